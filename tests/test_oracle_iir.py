@@ -1,0 +1,108 @@
+"""The CPU oracle's cascaded biquads pinned against the reference (casc_2o_iir.h).
+
+Bit-for-bit against fixtures from the REAL reference (tests/golden/iir_golden.npz) and the
+reference's own tests restated from test/testIIR.cpp: Octave CSV impulse responses at 1e-12
+(:59), block == whole bit-identical (:61-75), gain linearity (:79-171), preload (:173-218).
+"""
+import numpy as np
+import pytest
+
+from conftest import design, impulse_csvs, read_impulse_csv
+
+KINDS = {"lp": 1, "hp": 2, "bp": 3}
+
+
+def test_designed_coefficients_match_reference(oracle, iir_golden):
+    for tag in iir_golden["csv_names"]:
+        ftype, fs, f0, q = iir_golden[f"{tag}__params"]
+        f = oracle.iir(4)
+        design(f, int(ftype), f0, fs, q)
+        assert np.array_equal(f.a, iir_golden[f"{tag}__a"]), tag
+        assert np.array_equal(f.b, iir_golden[f"{tag}__b"]), tag
+        assert f.gain == float(iir_golden[f"{tag}__gain"]), tag
+
+
+def test_impulse_responses_bit_for_bit(oracle, iir_golden):
+    for tag in iir_golden["csv_names"]:
+        ftype, fs, f0, q = iir_golden[f"{tag}__params"]
+        x = np.zeros(1000)
+        x[0] = 1.0
+        for kind, key in ((0, "generic"), (int(ftype), "spec")):
+            f = oracle.iir(4)
+            design(f, int(ftype), f0, fs, q)
+            assert np.array_equal(f.process(x, kind), iir_golden[f"{tag}__{key}"]), (tag, key)
+            if kind == 0:
+                assert np.array_equal(f.mem, iir_golden[f"{tag}__generic_mem"])
+                assert f.pos == int(iir_golden[f"{tag}__generic_pos"])
+
+
+@pytest.mark.parametrize("csv", impulse_csvs(), ids=lambda p: p.stem)
+def test_octave_impulse_and_block_processing(oracle, csv):
+    # testIIR.cpp:32-75
+    ftype, fs, f0, q, want = read_impulse_csv(csv)
+    for kind in (0, ftype):
+        df = oracle.iir(4)
+        design(df, ftype, f0, fs, q)
+        df2 = df.copy()
+        data = np.zeros(want.size)
+        data[0] = 1.0
+        out = df.process(data, kind)
+        assert np.abs(out - want).max() < 1e-12
+        parts = [df2.process(data[i:i + 32], kind) for i in range(0, data.size, 32)]
+        assert np.array_equal(np.concatenate(parts), out)
+
+
+@pytest.mark.parametrize("nm", ["lp", "hp", "bp"])
+def test_gain_bench_random_and_preload_fixtures(oracle, iir_golden, nm):
+    ftype = KINDS[nm]
+    fs, f0, q = 100e3, 10e3, 1.1
+    imp = np.zeros(1024)
+    imp[0] = 1.0
+    outs = {}
+    for gain_in in (1.0, 2.0):
+        for kind, key in ((0, "generic"), (ftype, "spec")):
+            f = oracle.iir(4)
+            design(f, ftype, f0, fs, q, gain_in)
+            outs[gain_in, key] = f.process(imp, kind)
+            assert np.array_equal(outs[gain_in, key], iir_golden[f"gain_{nm}_{gain_in:g}__{key}"])
+    # testIIR.cpp:79-171: gain_in=2 == 2x output, 1e-12
+    assert np.abs(2.0 * outs[1.0, "generic"] - outs[2.0, "generic"]).max() < 1e-12
+    imp4096 = np.zeros(4096)
+    imp4096[0] = 1.0
+    for src, tag in ((imp4096, "bench4096"), (iir_golden["rand4096__in"], "rand4096")):
+        for kind, key in ((0, "generic"), (ftype, "spec")):
+            f = oracle.iir(4)
+            design(f, ftype, f0, fs, q)
+            assert np.array_equal(f.process(src, kind), iir_golden[f"{tag}_{nm}__{key}"])
+    # testIIR.cpp:173-218
+    f = oracle.iir(4)
+    design(f, ftype, f0, fs, q)
+    f.preload_filter(10.0)
+    assert np.array_equal(f.mem, iir_golden[f"preload_{nm}__mem"])
+    out = f.process(np.full(1024, 10.0))
+    assert np.array_equal(out, iir_golden[f"preload_{nm}__out"])
+    target = 10.0 if nm == "lp" else 0.0
+    assert np.abs(out - target).max() < 1e-12
+
+
+def test_other_section_counts(oracle, iir_golden):
+    xs = iir_golden["rand512__in"]
+    for m in (2, 6, 8):
+        for nm, ftype in KINDS.items():
+            for kind, key in ((0, "generic"), (ftype, "spec")):
+                f = oracle.iir(m)
+                design(f, ftype, 3e3, 48e3, 0.9)
+                assert np.array_equal(f.process(xs, kind), iir_golden[f"rand512_m{m}_{nm}__{key}"])
+    with pytest.raises(ValueError):
+        oracle.iir(3)  # static_assert casc_2o_iir.h:25
+
+
+def test_copy_coeff_from_copies_design_not_state(oracle):
+    # casc_2o_iir.h:28-34
+    a = oracle.iir(4)
+    a.set_hp_coeff(2e3, 39e3)
+    a.process(np.ones(10))
+    b = oracle.iir(4)
+    b.copy_coeff_from(a)
+    assert np.array_equal(a.a, b.a) and np.array_equal(a.b, b.b) and a.gain == b.gain
+    assert b.pos == 0 and not b.mem.any() and a.mem.any()
