@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Default workload = BASELINE.json configs[1]: batched N=4096 radix-4 complex FFT, batch 65536,
+fp32, in place, inputs resident in HBM before the timed region.  One "step" = one pass of the hot
+path over the batch (one kernel launch).  Steps alternate forward / reverse transforms so the
+in-place data stays finite and random-like for any K (same kernel template; the reverse adds the
+reference's 1/N scale, fft.h:128-132).  For N > 1 every rank owns a shard of the same size on its
+own GPU (weak scaling; the transforms are independent, so there is no data-path collective --
+torch.distributed is used for the start/stop barrier and the max-over-ranks time only).
+
+`roofline.achieved` = algorithmic bytes per launch (each element read once + written
+once) / average launch duration measured with HIP events on the launch stream inside this run.
+`cpu_baseline` = the reference's own CPU path (oracle/_ref, the real simpledsp headers; falls back
+to the oracle restatement, kind "port") timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64"])
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the per-GPU unit count")
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# workloads: each returns (step_fn, units_per_step, algorithmic_bytes_per_unit, describe dict)
+
+def make_fft4096(sd, torch, dev, args):
+    batch = args.batch_per_gpu or 65536
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + dev.index)
+    x = torch.view_as_complex(torch.randn((batch, 4096, 2), generator=g, device=dev, dtype=torch.float32))
+    fwd = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32, max_batch=batch, device=dev.index)
+    rev = sd.FftPlan(4096, 4, sd.reverse_fft, sd.F32, max_batch=batch, device=dev.index)
+    if args.variant >= 0:
+        fwd.set_variant(args.variant)
+        rev.set_variant(args.variant)
+    state = {"i": 0}
+
+    def step():
+        (fwd if state["i"] % 2 == 0 else rev).exec(x)
+        state["i"] += 1
+
+    info = fwd.info
+    desc = {
+        "workload": "BASELINE configs[1]: batched N=4096 radix-4 complex FFT, in place, fp32",
+        "n": 4096, "radix": 4, "batch_per_gpu": batch,
+        "direction": "forward/reverse alternating (keeps the in-place data finite)",
+        "kernel": info.kernel.decode(), "hbm_passes": info.hbm_passes,
+    }
+    return step, batch, int(info.algorithmic_bytes), desc, "batched complex FFTs/sec (N=4096, radix-4, fp32)", "FFT/s", "f32", (fwd, rev, x)
+
+
+def make_fft1m(sd, torch, dev, args):
+    batch = args.batch_per_gpu or 256
+    n = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 1 + dev.index)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device=dev, dtype=torch.float32))
+    fwd = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch, device=dev.index)
+    rev = sd.FftPlan(n, 2, sd.reverse_fft, sd.F32, max_batch=batch, device=dev.index)
+    state = {"i": 0}
+
+    def step():
+        (fwd if state["i"] % 2 == 0 else rev).exec(x)
+        state["i"] += 1
+
+    info = fwd.info
+    desc = {
+        "workload": "BASELINE configs[2]: batched N=2^20 radix-2 complex FFT, multi-pass HBM-resident, fp32",
+        "n": n, "radix": 2, "batch_per_gpu": batch, "kernel": info.kernel.decode(),
+        "hbm_passes": info.hbm_passes,
+    }
+    return step, batch, int(info.algorithmic_bytes), desc, "batched complex FFTs/sec (N=2^20, radix-2, fp32)", "FFT/s", "f32", (fwd, rev, x)
+
+
+def make_iir(sd, torch, dev, args, f64=False):
+    channels = args.batch_per_gpu or (1 << 20)
+    samples = 4096
+    dt = torch.float64 if f64 else torch.float32
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 2 + dev.index)
+    x = torch.randn((channels, samples), generator=g, device=dev, dtype=dt)
+    bank = sd.casc_2o_iir(4, channels, sd.F64 if f64 else sd.F32, sd.IIR_GENERIC, device=dev.index)
+    bank.set_lp_coeff(10e3, 100e3)  # testIIR.cpp:469-474
+    if args.variant >= 0:
+        bank.set_variant(args.variant)
+
+    def step():
+        bank.reset()
+        bank.process(x)  # unity-DC-gain low-pass: repeated filtering stays bounded
+
+    bank.reset()
+    desc = {
+        "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place",
+        "sections": 4, "channels_per_gpu": channels, "samples": samples,
+        "kernel": "sdsp_iir_tiled_kernel",
+    }
+    unit_bytes = 16 if f64 else 8
+    return step, channels * samples, unit_bytes, desc, "IIR samples/sec (4 cascaded biquads, LP)", "samples/s", "f64" if f64 else "f32", (bank, x)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own CPU path on this host's cores, bounded sample
+
+def cpu_baseline(workload: str, seconds: float):
+    import numpy as np
+    try:
+        from oracle import Oracle, Reference
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "", "cores": 0, "kind": "port", "sample": f"oracle unavailable: {e}"}
+    kind = "reference" if Reference.available() else "port"
+    be = Reference() if kind == "reference" else Oracle()
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
+    rng = np.random.default_rng(0x5D5B)
+    deadline = time.perf_counter() + seconds
+    counts = [0] * cores
+
+    if workload.startswith("fft"):
+        n, radix, per = (4096, 4, 64) if workload == "fft4096" else (4096, 2, 64)
+        if workload == "fft1m" and kind == "port":
+            n, radix, per = 1 << 20, 2, 1
+        bufs = [(rng.standard_normal((per, n)) + 1j * rng.standard_normal((per, n))).astype(np.complex128)
+                for _ in range(cores)]
+        if kind == "port":
+            be.fft_inplace(bufs[0][:1].copy(), radix)  # build the plan outside the timed region
+
+        def work(i):
+            a = bufs[i]
+            while time.perf_counter() < deadline:
+                a[:] = bufs[i]  # fresh (finite) input each pass, as the reference BENCHMARK does (testFFT.cpp:243)
+                be.fft_inplace(a, radix)
+                counts[i] += per
+        unit = "FFT/s"
+        sample = f"N={n} radix-{radix} complex128 forward, {per} transforms per pass per thread, ~{seconds:.0f} s wall"
+    else:
+        per = 16
+        if kind == "reference":
+            filt = [be.iir(4, 0) for _ in range(cores)]
+        else:
+            filt = [be.iir(4) for _ in range(cores)]
+        for f in filt:
+            f.set_lp_coeff(10e3, 100e3)
+        bufs = [rng.standard_normal((per, 4096)) for _ in range(cores)]
+
+        def work(i):
+            a = bufs[i].copy()
+            while time.perf_counter() < deadline:
+                for r in range(per):
+                    filt[i].process_inplace(a[r])
+                counts[i] += per * 4096
+        unit = "samples/s"
+        sample = f"casc_2o_iir<4> LP, 4096-sample blocks (testIIR.cpp:482-487), float64, ~{seconds:.0f} s wall"
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": unit, "cores": cores, "kind": kind,
+            "sample": sample + f"; {cores} threads, float64 (the reference's precision)"}
+
+
+def read_traffic(kernel_prefix: str):
+    """HBM bytes per launch from a committed PMC summary (profiles/traffic.json), or None."""
+    p = ROOT / "profiles" / "traffic.json"
+    try:
+        t = json.loads(p.read_text())
+        for k, v in t.items():
+            if kernel_prefix.startswith(k) or k.startswith(kernel_prefix):
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import simpledsp_amd as sd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the product path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    sd.load()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    mk = {"fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
+          "iir64": lambda *a: make_iir(*a, f64=True)}[args.workload]
+    step, units, unit_bytes, desc, metric, unit, dtype, keep = mk(sd, torch, dev, args)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # HIP events on the launch stream
+    if dist:
+        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        total_units = units * world * args.steps
+        value = total_units / wall
+        achieved = units * unit_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {**desc, "parallelism": f"batch-shard x{world}, no collective"},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"]),
+                "kernel": desc["kernel"], "avg_launch_ms": kern_ms,
+                "algorithmic_bytes_per_launch": units * unit_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del keep
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            if out["cpu_baseline"]["value"]:
+                out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * sdsp_hip.h -- C ABI of the MI355X (gfx950) batched-FFT + cascaded-biquad engine.
+ *
+ * This is the drop-in boundary for simpledsp's FFT/IIR hot path.  The reference has no FFI
+ * layer of its own: its boundary is the header-only C++ surface (include/sdsp/fft.h,
+ * include/sdsp/casc_2o_iir.h).  The sdsp:: headers shipped in include/sdsp/ keep that surface
+ * and call the entry points below; each entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout).  Plain pointers and sizes only -- no torch, no
+ * C++ types.  `stream` arguments are hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Conventions
+ *   - every function returns an sdsp_hip_status (0 = ok, negative = error); a human-readable
+ *     description of the calling thread's last error: sdsp_hip_last_error_string().
+ *   - the caller owns all data buffers; transforms and filters run IN PLACE (fft.h:259,302;
+ *     casc_2o_iir.h:37,71).  Plans own twiddles/coefficients/workspaces on their device.
+ *   - complex data is interleaved (re,im), the layout of std::complex (fft.h:51-52).
+ *   - there is no CPU fallback: without a usable HIP device the compute calls fail with
+ *     SDSP_HIP_ERR_NO_DEVICE / SDSP_HIP_ERR_HIP.
+ *   - distinct plans may be used from distinct host threads concurrently.
+ */
+#ifndef SDSP_HIP_H
+#define SDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SDSP_HIP_OK = 0,
+    SDSP_HIP_ERR_INVALID_SIZE = -1, /* replaces static_assert fft.h:261,304 / casc_2o_iir.h:25 */
+    SDSP_HIP_ERR_UNSUPPORTED = -2,
+    SDSP_HIP_ERR_HIP = -3,
+    SDSP_HIP_ERR_NO_DEVICE = -4,
+    SDSP_HIP_ERR_INVALID_ARG = -5,
+    SDSP_HIP_ERR_NOMEM = -6
+} sdsp_hip_status;
+
+typedef enum { SDSP_HIP_F32 = 0, SDSP_HIP_F64 = 1 } sdsp_hip_precision;
+/* forward_fft / reverse_fft policy, fft.h:121-146 (reverse: conjugate twiddles and 1/N scale) */
+typedef enum { SDSP_HIP_FORWARD = 1, SDSP_HIP_REVERSE = -1 } sdsp_hip_direction;
+/* filter_type.h:6 -- the same integer values */
+typedef enum {
+    SDSP_HIP_FILTER_NONE = 0,
+    SDSP_HIP_FILTER_LOW_PASS = 1,
+    SDSP_HIP_FILTER_HIGH_PASS = 2,
+    SDSP_HIP_FILTER_BAND_PASS = 3
+} sdsp_hip_filter_type;
+/* which process() body runs: casc_2o_iir::process (casc_2o_iir.h:36-80) or the
+ * numerator-folded casc_2o_iir_{lp,hp,bp}::process_spec (:286-295, :344-353, :402-411) */
+typedef enum {
+    SDSP_HIP_IIR_GENERIC = 0,
+    SDSP_HIP_IIR_LP = 1,
+    SDSP_HIP_IIR_HP = 2,
+    SDSP_HIP_IIR_BP = 3
+} sdsp_hip_iir_kind;
+
+#define SDSP_HIP_MAX_SECTIONS 16
+
+typedef struct sdsp_hip_fft_plan sdsp_hip_fft_plan;
+typedef struct sdsp_hip_iir_plan sdsp_hip_iir_plan;
+
+/* ------------------------------------------------------------------ runtime */
+
+const char *sdsp_hip_last_error_string(void);
+const char *sdsp_hip_version(void);
+int sdsp_hip_device_count(int *count);
+/* device memory helpers so that a C/C++ host can stay free of <hip/hip_runtime.h> */
+int sdsp_hip_malloc(void **dev_ptr, size_t bytes, int device);
+int sdsp_hip_free(void *dev_ptr, int device);
+int sdsp_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, int device);
+int sdsp_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, int device);
+int sdsp_hip_device_synchronize(int device);
+
+/* ------------------------------------------------------------------ size helpers, fft.h:12-43 */
+
+unsigned sdsp_hip_log2(unsigned num);
+unsigned sdsp_hip_log4(unsigned num);
+int sdsp_hip_is_power_of_2(unsigned num);
+int sdsp_hip_is_power_of_4(unsigned num);
+/* digit_reverse<N,base>, fft.h:217-236 (the GPU folds this into load/store addressing) */
+unsigned sdsp_hip_digit_reverse(unsigned n, unsigned base, unsigned x);
+/* one row of the run-time twiddle precompute that replaces the compile-time calc_wCoeffs
+ * (fft.h:197-214): out[j] = exp(-/+ 2*pi*i*j/n), j in [0,n), n interleaved complex doubles,
+ * first quadrant from libm, the rest by exact mirror symmetry (fft.h:148-194). */
+int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
+
+/* ------------------------------------------------------------------ FFT */
+
+/*
+ * Replaces sdsp::fft_radix2<T,N> (fft.h:258-299, radix = 2, n a power of 2) and
+ * sdsp::fft_radix4<T,N> (fft.h:301-360, radix = 4, n a power of 4) for a BATCH of transforms.
+ * n must satisfy the radix (else SDSP_HIP_ERR_INVALID_SIZE -- the run-time form of the
+ * reference's static_asserts).  `max_batch` sizes the plan-owned workspace that transforms too
+ * large for on-chip memory need (n > 16384 in f32, n > 8192 in f64); larger batches are
+ * processed in slices of max_batch.  Twiddles are precomputed in double, rounded once to the
+ * plan precision and kept resident in HBM.
+ */
+int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n, int radix, int direction,
+                             int precision, uint64_t max_batch, int device);
+int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *plan);
+
+/* data: DEVICE pointer, batch x n interleaved complex of the plan precision, transformed in
+ * place.  Asynchronous on `stream`. */
+int sdsp_hip_fft_exec(sdsp_hip_fft_plan *plan, void *data, uint64_t batch, void *stream);
+/* same with a HOST pointer: H2D, transform, D2H, synchronous (the single-call drop-in path) */
+int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *plan, void *host_data, uint64_t batch);
+/* contiguous batch split over `n_plans` devices (one plan per device, same n/radix/direction/
+ * precision), one host thread + stream per device, no collective: SURVEY 8(e) */
+int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void *host_data,
+                              uint64_t batch);
+
+typedef struct {
+    uint32_t n;
+    int radix;
+    int direction;
+    int precision;
+    int device;
+    int hbm_passes;              /* 1: one read + one write per element; 2: four-step */
+    uint64_t algorithmic_bytes;  /* per transform: n * sizeof(complex) * 2 (read + write once) */
+    uint64_t workspace_bytes;
+    uint64_t twiddle_bytes;
+    char kernel[64];             /* name of the dominant kernel (for rocprofv3 matching) */
+} sdsp_hip_fft_plan_info;
+int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *plan, sdsp_hip_fft_plan_info *info);
+/* copy the plan's resident twiddle row W_n^j (plan precision, n complex) back to the host */
+int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out);
+/* choose among kernel variants of a plan (tuning/testing); variant 0 is the default */
+int sdsp_hip_fft_plan_set_variant(sdsp_hip_fft_plan *plan, int variant);
+
+/* ------------------------------------------------------------------ cascaded biquads */
+
+/*
+ * Coefficient design (host, double) -- set_lp_coeff / set_hp_coeff / set_bp_coeff,
+ * casc_2o_iir.h:168-194, :140-166, :82-138 (identical in the specialised classes :297-467).
+ * sections = m_t (even).  Outputs: a[sections*3], b[sections*3], *gain (= m_gain).
+ */
+int sdsp_hip_iir_design_lp(uint32_t sections, double f0, double fs, double gain_in, double *a,
+                           double *b, double *gain);
+int sdsp_hip_iir_design_hp(uint32_t sections, double f0, double fs, double gain_in, double *a,
+                           double *b, double *gain);
+int sdsp_hip_iir_design_bp(uint32_t sections, double f0, double fs, double q, double gain_in,
+                           double *a, double *b, double *gain);
+/* preload_filter, casc_2o_iir.h:197-214: mem[(sections+1)*3] for a steady input `value` */
+int sdsp_hip_iir_preload(uint32_t sections, int filter_type, const double *a, const double *b,
+                         double gain, double value, double *mem);
+
+/*
+ * A bank of identical cascades (shared coefficients, per-channel state) -- the batched form of
+ * sdsp::casc_2o_iir<m_t> (kind GENERIC) and sdsp::casc_2o_iir_{lp,hp,bp}<m_t>.
+ * a: sections*3, b: sections*3 (may be NULL for the specialised kinds), gain: m_gain.
+ */
+int sdsp_hip_iir_plan_create(sdsp_hip_iir_plan **plan, uint32_t sections, int kind,
+                             const double *a, const double *b, double gain, int precision,
+                             int device);
+int sdsp_hip_iir_plan_destroy(sdsp_hip_iir_plan *plan);
+
+/*
+ * process(): casc_2o_iir.h:36-80 / :228-263 for `channels` independent streams.
+ * data: DEVICE pointer; channel c's samples are data[c*stride + 0 .. samples) (channel-major,
+ * each channel is what one reference process() call sees), filtered in place.
+ * state: DEVICE pointer or NULL.  NULL = every channel starts from a zero-initialised filter
+ *   and the final state is dropped.  Otherwise state[(3*(sections+1)) * channels] of the plan
+ *   precision, laid out state[(3*j + age) * channels + c] = y_j[n-1-age] of channel c
+ *   (j = 0 is the gain-scaled input history, j = sections the output history, age 0..2):
+ *   the reference's m_mem ring (casc_2o_iir.h:15) rotated so that m_pos is implicit.  Read at
+ *   entry, written at exit, so consecutive calls continue the stream bit-identically
+ *   (testIIR.cpp:61-75).
+ */
+int sdsp_hip_iir_process(sdsp_hip_iir_plan *plan, void *data, uint64_t channels,
+                         uint64_t samples, uint64_t stride, void *state, void *stream);
+/* same with HOST pointers (synchronous) */
+int sdsp_hip_iir_process_host(sdsp_hip_iir_plan *plan, void *host_data, uint64_t channels,
+                              uint64_t samples, uint64_t stride, void *host_state);
+/* contiguous channel range split over devices, no collective */
+int sdsp_hip_iir_process_sharded(sdsp_hip_iir_plan *const *plans, int n_plans, void *host_data,
+                                 uint64_t channels, uint64_t samples);
+/* bytes of a state buffer for `channels` channels */
+int sdsp_hip_iir_state_bytes(const sdsp_hip_iir_plan *plan, uint64_t channels, uint64_t *bytes);
+int sdsp_hip_iir_plan_set_variant(sdsp_hip_iir_plan *plan, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDSP_HIP_H */

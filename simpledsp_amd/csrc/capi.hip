@@ -1,0 +1,645 @@
+// capi.hip -- the extern "C" boundary declared in include/sdsp_hip.h: plans, launches, host and
+// multi-device convenience paths.  Everything that computes goes to the HIP kernels in
+// fft_tile.hip / fft4096.hip / iir.hip; there is no CPU implementation behind these entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "sdsp_hip_internal.h"
+
+using namespace sdsp_hip;
+
+namespace
+{
+int hip_fail(hipError_t e, const char *what)
+{
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+        return fail(SDSP_HIP_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return fail(SDSP_HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess)                  \
+            return hip_fail(_e, #expr);        \
+    } while (0)
+
+int use_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(SDSP_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= count)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return SDSP_HIP_OK;
+}
+
+size_t esize(int precision) { return precision == SDSP_HIP_F64 ? 16 : 8; } // one complex element
+
+// round a double table to the plan precision and park it in HBM
+int upload_twiddles(const std::vector<double> &w, int precision, void **dev)
+{
+    const size_t n = w.size() / 2;
+    if (precision == SDSP_HIP_F64) {
+        HIP_TRY(hipMalloc(dev, n * 16));
+        HIP_TRY(hipMemcpy(*dev, w.data(), n * 16, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> wf(w.size());
+        for (size_t i = 0; i < w.size(); i++)
+            wf[i] = (float)w[i];
+        HIP_TRY(hipMalloc(dev, n * 8));
+        HIP_TRY(hipMemcpy(*dev, wf.data(), n * 8, hipMemcpyHostToDevice));
+    }
+    return SDSP_HIP_OK;
+}
+
+enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3 };
+} // namespace
+
+struct sdsp_hip_fft_plan {
+    uint32_t n = 0;
+    int radix = 0, direction = 0, precision = 0, device = 0;
+    uint64_t max_batch = 0;
+    int path = PATH_NOOP;
+    int variant = 0;
+    void *tw = nullptr;            // W_n (single pass) or W_N (four-step inter-pass twiddle)
+    void *tw1 = nullptr;           // four-step: W_n1
+    void *tw2 = nullptr;           // four-step: W_n2
+    uint32_t n1 = 0, n2 = 0;       // four-step split
+    uint32_t cols = 1, pitch = 1;  // tile shape (single pass)
+    uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
+    void *workspace = nullptr;
+    uint64_t workspace_bytes = 0;
+    uint64_t twiddle_bytes = 0;
+    void *host_stage = nullptr;    // device staging buffer of the *_host path
+    uint64_t host_stage_bytes = 0;
+};
+
+struct sdsp_hip_iir_plan {
+    uint32_t sections = 0;
+    int kind = 0, precision = 0, device = 0, variant = 0;
+    double gain = 1.0;
+    double a[3 * SDSP_HIP_MAX_SECTIONS] = {};
+    double b[3 * SDSP_HIP_MAX_SECTIONS] = {};
+};
+
+namespace
+{
+// largest power-of-two column count whose padded tile fits the LDS budget
+void pick_tile(int precision, uint32_t n, uint32_t want_cols, uint32_t *cols, uint32_t *pitch)
+{
+    uint32_t c = want_cols;
+    while (c > 1 && fft_tile_lds_bytes(precision, n, c + 1) > fft_tile_max_lds_bytes())
+        c >>= 1;
+    *cols = c;
+    *pitch = c > 1 ? c + 1 : 1; // odd pitch: both access orders spread over the banks
+}
+
+int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream)
+{
+    if (batch == 0 || p->path == PATH_NOOP)
+        return SDSP_HIP_OK;
+    const bool rev = p->direction == SDSP_HIP_REVERSE;
+
+    if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants()) {
+        fft4096_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.batch = batch;
+        a.scale = 1.0f / 4096.0f;
+        a.reverse = rev;
+        return launch_fft4096_r4_f32(a, p->variant, stream);
+    }
+
+    if (p->path == PATH_TILE || p->path == PATH_FFT4096) {
+        fft_tile_args a{};
+        a.in = data;
+        a.out = data;
+        a.tw = p->tw;
+        a.tw_big = nullptr;
+        a.n = p->n;
+        a.log2n = sdsp_hip_log2(p->n);
+        a.cols = p->cols;
+        a.pitch = p->pitch;
+        a.total_cols = batch;
+        a.tiles_per_group = 1;
+        a.group_stride = (uint64_t)p->cols * p->n;
+        a.in_tile_step = a.out_tile_step = 0;
+        a.in_si = a.out_sk = 1;
+        a.in_sc = a.out_sc = p->n;
+        a.in_c_fast = a.out_c_fast = 0;
+        a.reverse = rev;
+        a.apply_scale = rev;
+        a.scale = (float)(1.0 / p->n);
+        a.scale_d = 1.0 / p->n;
+        const uint64_t tiles = (batch + p->cols - 1) / p->cols;
+        return launch_fft_tile(p->precision, p->radix, a, tiles, stream);
+    }
+
+    // four-step: N = n1 x n2 viewed as a row-major [n1][n2] matrix (index n = n2_count*i1 + i2).
+    //   pass 1: length-n1 transforms down the columns, times W_N^(i2*k1), data -> workspace
+    //   pass 2: length-n2 transforms along the rows, written transposed, workspace -> data
+    const uint64_t N = (uint64_t)p->n1 * p->n2;
+    uint64_t done = 0;
+    while (done < batch) {
+        const uint64_t nb = std::min<uint64_t>(p->max_batch, batch - done);
+        char *d = reinterpret_cast<char *>(data) + done * N * esize(p->precision);
+        fft_tile_args a{};
+        a.in = d;
+        a.out = p->workspace;
+        a.tw = p->tw1;
+        a.tw_big = p->tw;
+        a.n = p->n1;
+        a.log2n = sdsp_hip_log2(p->n1);
+        a.cols = p->cols1;
+        a.pitch = p->pitch1;
+        a.tiles_per_group = p->n2 / p->cols1;
+        a.total_cols = nb * p->n2;
+        a.group_stride = N;
+        a.in_tile_step = a.out_tile_step = p->cols1;
+        a.in_si = a.out_sk = p->n2;
+        a.in_sc = a.out_sc = 1;
+        a.in_c_fast = a.out_c_fast = 1;
+        a.reverse = rev;
+        a.apply_scale = 0;
+        a.scale = 1.0f;
+        a.scale_d = 1.0;
+        int rc = launch_fft_tile(p->precision, p->radix, a, nb * a.tiles_per_group, stream);
+        if (rc)
+            return rc;
+
+        fft_tile_args c{};
+        c.in = p->workspace;
+        c.out = d;
+        c.tw = p->tw2;
+        c.tw_big = nullptr;
+        c.n = p->n2;
+        c.log2n = sdsp_hip_log2(p->n2);
+        c.cols = p->cols2;
+        c.pitch = p->pitch2;
+        c.tiles_per_group = p->n1 / p->cols2;
+        c.total_cols = nb * p->n1;
+        c.group_stride = N;
+        c.in_tile_step = (uint64_t)p->cols2 * p->n2;
+        c.out_tile_step = p->cols2;
+        c.in_si = 1;
+        c.in_sc = p->n2;
+        c.in_c_fast = 0;
+        c.out_sk = p->n1;
+        c.out_sc = 1;
+        c.out_c_fast = 1;
+        c.reverse = rev;
+        c.apply_scale = rev;
+        c.scale = (float)(1.0 / (double)N);
+        c.scale_d = 1.0 / (double)N;
+        rc = launch_fft_tile(p->precision, p->radix, c, nb * c.tiles_per_group, stream);
+        if (rc)
+            return rc;
+        done += nb;
+    }
+    return SDSP_HIP_OK;
+}
+} // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ runtime
+
+int sdsp_hip_device_count(int *count)
+{
+    if (!count)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = e == hipSuccess ? c : 0;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_malloc(void **dev_ptr, size_t bytes, int device)
+{
+    if (!dev_ptr)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "dev_ptr is null");
+    if (int rc = use_device(device))
+        return rc;
+    HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_free(void *dev_ptr, int device)
+{
+    if (!dev_ptr)
+        return SDSP_HIP_OK;
+    if (int rc = use_device(device))
+        return rc;
+    HIP_TRY(hipFree(dev_ptr));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, int device)
+{
+    if (int rc = use_device(device))
+        return rc;
+    HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, int device)
+{
+    if (int rc = use_device(device))
+        return rc;
+    HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_device_synchronize(int device)
+{
+    if (int rc = use_device(device))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return SDSP_HIP_OK;
+}
+
+// ------------------------------------------------------------------ FFT plans
+
+int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int direction, int precision,
+                             uint64_t max_batch, int device)
+{
+    if (!out)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
+    *out = nullptr;
+    // the reference's static_asserts (fft.h:261, :304) as run-time checks
+    if (radix == 2) {
+        if (!sdsp_hip_is_power_of_2(n))
+            return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
+    } else if (radix == 4) {
+        if (!sdsp_hip_is_power_of_4(n))
+            return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT radix 4 size must be a power of 4!");
+    } else {
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix must be 2 or 4");
+    }
+    if (direction != SDSP_HIP_FORWARD && direction != SDSP_HIP_REVERSE)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "direction must be SDSP_HIP_FORWARD or SDSP_HIP_REVERSE");
+    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32 or SDSP_HIP_F64");
+    if (n > (1u << 24))
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "FFT sizes above 2^24 are not supported");
+    if (int rc = use_device(device))
+        return rc;
+
+    auto *p = new sdsp_hip_fft_plan();
+    p->n = n;
+    p->radix = radix;
+    p->direction = direction;
+    p->precision = precision;
+    p->device = device;
+    p->max_batch = max_batch ? max_batch : 1;
+
+    int rc = SDSP_HIP_OK;
+    std::vector<double> w;
+    const uint32_t lds_cap_n = (uint32_t)(fft_tile_max_lds_bytes() / esize(precision));
+    if (n == 1) {
+        p->path = PATH_NOOP;
+    } else if (n <= lds_cap_n) {
+        p->path = (n == 4096 && radix == 4 && precision == SDSP_HIP_F32) ? PATH_FFT4096 : PATH_TILE;
+        make_twiddles(n, direction, w);
+        rc = upload_twiddles(w, precision, &p->tw);
+        p->twiddle_bytes = (uint64_t)n * esize(precision);
+        pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
+        if (p->cols > 16)
+            pick_tile(precision, n, 16, &p->cols, &p->pitch);
+    } else {
+        p->path = PATH_FOUR_STEP;
+        const uint32_t k = sdsp_hip_log2(n);
+        if (radix == 2) {
+            p->n1 = 1u << ((k + 1) / 2);
+        } else {
+            const uint32_t d = k / 2;
+            p->n1 = 1u << (2 * ((d + 1) / 2));
+        }
+        p->n2 = n / p->n1;
+        make_twiddles(n, direction, w);
+        rc = upload_twiddles(w, precision, &p->tw);
+        if (!rc) {
+            make_twiddles(p->n1, direction, w);
+            rc = upload_twiddles(w, precision, &p->tw1);
+        }
+        if (!rc) {
+            make_twiddles(p->n2, direction, w);
+            rc = upload_twiddles(w, precision, &p->tw2);
+        }
+        p->twiddle_bytes = ((uint64_t)n + p->n1 + p->n2) * esize(precision);
+        pick_tile(precision, p->n1, 16, &p->cols1, &p->pitch1);
+        pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
+        p->workspace_bytes = p->max_batch * n * esize(precision);
+        if (!rc) {
+            hipError_t e = hipMalloc(&p->workspace, p->workspace_bytes);
+            if (e != hipSuccess)
+                rc = fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    if (rc) {
+        sdsp_hip_fft_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
+{
+    if (!p)
+        return SDSP_HIP_OK;
+    if (hipSetDevice(p->device) == hipSuccess) {
+        (void)hipFree(p->tw);
+        (void)hipFree(p->tw1);
+        (void)hipFree(p->tw2);
+        (void)hipFree(p->workspace);
+        (void)hipFree(p->host_stage);
+    }
+    delete p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_exec(sdsp_hip_fft_plan *p, void *data, uint64_t batch, void *stream)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (batch == 0)
+        return SDSP_HIP_OK;
+    if (!data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if ((uintptr_t)data % esize(p->precision) != 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data must be aligned to one complex element");
+    if (int rc = use_device(p->device))
+        return rc;
+    return fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream));
+}
+
+int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *p, void *host_data, uint64_t batch)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (batch == 0)
+        return SDSP_HIP_OK;
+    if (!host_data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (int rc = use_device(p->device))
+        return rc;
+    const uint64_t bytes = batch * p->n * esize(p->precision);
+    if (bytes > p->host_stage_bytes) {
+        (void)hipFree(p->host_stage);
+        p->host_stage = nullptr;
+        p->host_stage_bytes = 0;
+        hipError_t e = hipMalloc(&p->host_stage, bytes);
+        if (e != hipSuccess)
+            return fail(SDSP_HIP_ERR_NOMEM, std::string("staging hipMalloc: ") + hipGetErrorString(e));
+        p->host_stage_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpy(p->host_stage, host_data, bytes, hipMemcpyHostToDevice));
+    if (int rc = fft_exec_device(p, p->host_stage, batch, nullptr))
+        return rc;
+    HIP_TRY(hipMemcpy(host_data, p->host_stage, bytes, hipMemcpyDeviceToHost));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void *host_data, uint64_t batch)
+{
+    if (!plans || n_plans <= 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "no plans");
+    for (int i = 0; i < n_plans; i++) {
+        if (!plans[i])
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "null plan in shard list");
+        if (plans[i]->n != plans[0]->n || plans[i]->radix != plans[0]->radix ||
+            plans[i]->direction != plans[0]->direction || plans[i]->precision != plans[0]->precision)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "shard plans must describe the same transform");
+    }
+    if (batch == 0)
+        return SDSP_HIP_OK;
+    if (!host_data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    // contiguous ranges [g*B/G, (g+1)*B/G): independent transforms, no exchange step
+    const size_t per = (size_t)plans[0]->n * esize(plans[0]->precision);
+    std::vector<int> rcs(n_plans, 0);
+    std::vector<std::string> errs(n_plans);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_plans; g++) {
+        const uint64_t lo = batch * g / n_plans, hi = batch * (g + 1) / n_plans;
+        th.emplace_back([=, &rcs, &errs] {
+            rcs[g] = sdsp_hip_fft_exec_host(plans[g], reinterpret_cast<char *>(host_data) + lo * per, hi - lo);
+            if (rcs[g])
+                errs[g] = g_last_error;
+        });
+    }
+    for (auto &t : th)
+        t.join();
+    for (int g = 0; g < n_plans; g++)
+        if (rcs[g])
+            return fail(rcs[g], errs[g]);
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_info *info)
+{
+    if (!p || !info)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    std::memset(info, 0, sizeof(*info));
+    info->n = p->n;
+    info->radix = p->radix;
+    info->direction = p->direction;
+    info->precision = p->precision;
+    info->device = p->device;
+    info->hbm_passes = p->path == PATH_FOUR_STEP ? 2 : 1;
+    info->algorithmic_bytes = 2ull * p->n * esize(p->precision);
+    info->workspace_bytes = p->workspace_bytes;
+    info->twiddle_bytes = p->twiddle_bytes;
+    const char *name = "sdsp_fft_tile_kernel";
+    if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants())
+        name = fft4096_kernel_name(p->variant);
+    std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *p, void *host_out)
+{
+    if (!p || !host_out)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    if (!p->tw)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "plan has no twiddle table");
+    if (int rc = use_device(p->device))
+        return rc;
+    HIP_TRY(hipMemcpy(host_out, p->tw, (size_t)p->n * esize(p->precision), hipMemcpyDeviceToHost));
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_plan_set_variant(sdsp_hip_fft_plan *p, int variant)
+{
+    if (!p || variant < 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "bad argument");
+    p->variant = variant;
+    return SDSP_HIP_OK;
+}
+
+// ------------------------------------------------------------------ IIR banks
+
+int sdsp_hip_iir_plan_create(sdsp_hip_iir_plan **out, uint32_t sections, int kind, const double *a,
+                             const double *b, double gain, int precision, int device)
+{
+    if (!out)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
+    *out = nullptr;
+    if (sections == 0 || sections % 2 != 0) // static_assert casc_2o_iir.h:25
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "M must be even!");
+    if (sections > 8)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "at most 8 sections are compiled in");
+    if (kind < SDSP_HIP_IIR_GENERIC || kind > SDSP_HIP_IIR_BP)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
+    if (!a || (kind == SDSP_HIP_IIR_GENERIC && !b))
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "coefficient pointer is null");
+    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32 or SDSP_HIP_F64");
+    if (int rc = use_device(device))
+        return rc;
+    auto *p = new sdsp_hip_iir_plan();
+    p->sections = sections;
+    p->kind = kind;
+    p->precision = precision;
+    p->device = device;
+    p->gain = gain;
+    std::memcpy(p->a, a, sizeof(double) * 3 * sections);
+    if (b)
+        std::memcpy(p->b, b, sizeof(double) * 3 * sections);
+    *out = p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_iir_plan_destroy(sdsp_hip_iir_plan *p)
+{
+    delete p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_iir_state_bytes(const sdsp_hip_iir_plan *p, uint64_t channels, uint64_t *bytes)
+{
+    if (!p || !bytes)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    *bytes = 3ull * (p->sections + 1) * channels * (p->precision == SDSP_HIP_F64 ? 8 : 4);
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_iir_plan_set_variant(sdsp_hip_iir_plan *p, int variant)
+{
+    if (!p || variant < 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "bad argument");
+    p->variant = variant;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_iir_process(sdsp_hip_iir_plan *p, void *data, uint64_t channels, uint64_t samples, uint64_t stride,
+                         void *state, void *stream)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (stride < samples && channels > 1)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "stride must be >= samples");
+    if (int rc = use_device(p->device))
+        return rc;
+    iir_args a{};
+    a.data = data;
+    a.state = state;
+    a.channels = channels;
+    a.samples = samples;
+    a.stride = stride;
+    a.sections = p->sections;
+    a.kind = p->kind;
+    a.gain = p->gain;
+    for (uint32_t j = 0; j < p->sections; j++) {
+        a.a1[j] = p->a[3 * j + 1];
+        a.a2[j] = p->a[3 * j + 2];
+        a.b1[j] = p->b[3 * j + 1];
+        a.b2[j] = p->b[3 * j + 2];
+    }
+    return launch_iir(p->precision, a, p->variant, stream);
+}
+
+int sdsp_hip_iir_process_host(sdsp_hip_iir_plan *p, void *host_data, uint64_t channels, uint64_t samples,
+                              uint64_t stride, void *host_state)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!host_data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (int rc = use_device(p->device))
+        return rc;
+    const size_t rs = p->precision == SDSP_HIP_F64 ? 8 : 4;
+    const size_t data_bytes = ((channels - 1) * stride + samples) * rs;
+    uint64_t state_bytes = 0;
+    sdsp_hip_iir_state_bytes(p, channels, &state_bytes);
+    void *d = nullptr, *s = nullptr;
+    HIP_TRY(hipMalloc(&d, data_bytes));
+    int rc = SDSP_HIP_OK;
+    hipError_t e = hipMemcpy(d, host_data, data_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && host_state) {
+        e = hipMalloc(&s, state_bytes);
+        if (e == hipSuccess)
+            e = hipMemcpy(s, host_state, state_bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess)
+        rc = hip_fail(e, "iir host staging");
+    if (!rc)
+        rc = sdsp_hip_iir_process(p, d, channels, samples, stride, s, nullptr);
+    if (!rc) {
+        e = hipMemcpy(host_data, d, data_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && host_state)
+            e = hipMemcpy(host_state, s, state_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = hip_fail(e, "iir host read-back");
+    }
+    (void)hipFree(d);
+    (void)hipFree(s);
+    return rc;
+}
+
+int sdsp_hip_iir_process_sharded(sdsp_hip_iir_plan *const *plans, int n_plans, void *host_data, uint64_t channels,
+                                 uint64_t samples)
+{
+    if (!plans || n_plans <= 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "no plans");
+    for (int i = 0; i < n_plans; i++)
+        if (!plans[i] || plans[i]->precision != plans[0]->precision || plans[i]->sections != plans[0]->sections)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "shard plans must describe the same filter bank");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!host_data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    const size_t row = samples * (plans[0]->precision == SDSP_HIP_F64 ? 8 : 4);
+    std::vector<int> rcs(n_plans, 0);
+    std::vector<std::string> errs(n_plans);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_plans; g++) {
+        const uint64_t lo = channels * g / n_plans, hi = channels * (g + 1) / n_plans;
+        th.emplace_back([=, &rcs, &errs] {
+            rcs[g] = sdsp_hip_iir_process_host(plans[g], reinterpret_cast<char *>(host_data) + lo * row, hi - lo,
+                                               samples, samples, nullptr);
+            if (rcs[g])
+                errs[g] = g_last_error;
+        });
+    }
+    for (auto &t : th)
+        t.join();
+    for (int g = 0; g < n_plans; g++)
+        if (rcs[g])
+            return fail(rcs[g], errs[g]);
+    return SDSP_HIP_OK;
+}
+}

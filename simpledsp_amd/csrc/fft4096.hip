@@ -1,0 +1,324 @@
+// fft4096.hip -- batched N = 4096 radix-4 complex f32 FFT for gfx950 (BASELINE configs 2 and 5).
+//
+// GPU form of sdsp::fft_radix4<T,4096> (fft.h:301-360): the same six radix-4 DIF stages
+// (fft.h:311-349), the +-i rotations done by swap/negate (fft.h:339-345), the base-4 digit
+// reversal (fft.h:351-355) and the reverse-direction 1/N scale (fft.h:128-132) -- organised for
+// the machine instead of for a scalar core:
+//
+//   * one 256-thread workgroup per transform, 16 points per thread in registers; the six stages
+//     run as three register passes of two stages each (strides 1024/256, 64/16, 4/1) with two
+//     exchanges through a 32 KiB LDS tile.  The tile is XOR-swizzled (addr = p ^ f(p >> 8)) so that
+//     every ds_write_b64 / ds_read_b64 / ds_read_b128 of all three access patterns is bank-conflict
+//     free without padding; the butterflies are in place, so a thread rewrites only slots it read.
+//   * the twiddle W_N^(r*pos) that stage s owes stage s+1 factors into a per-thread part that is the
+//     same for every transform (W^(r*t): 12 complex values, fetched ONCE per workgroup from the
+//     HBM-resident table the plan precomputed in double) and a compile-time W_16 constant.  No
+//     twiddle traffic per transform.
+//   * the digit reversal costs nothing: the last pass is assigned so that thread t holds the block
+//     whose outputs land at t + 256*j, i.e. stores are as coalesced as the loads (512 contiguous
+//     bytes per wave instruction both ways) and HBM sees every element exactly once each way.
+//   * workgroups are persistent (grid = resident capacity) and fetch transform i+1 into registers
+//     while transform i is in its second and third pass, so every wave always has loads in flight.
+//
+// HBM-bound by design: 64 KiB of traffic against ~250 kflop per transform.  No MFMA.
+#include <hip/hip_runtime.h>
+
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+constexpr float kC1 = 0.92387953251128673848f; // cos(pi/8)
+constexpr float kS1 = 0.38268343236508978178f; // sin(pi/8)
+constexpr float kH = 0.70710678118654752440f;  // sqrt(1/2)
+
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return float2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
+}
+// a * (cr -/+ i*ci): compile-time constant, conjugated for the reverse transform
+template <bool REV> __device__ __forceinline__ float2 cmulk(float2 a, float cr, float ci_fwd)
+{
+    const float ci = REV ? -ci_fwd : ci_fwd;
+    return float2{ a.x * cr - a.y * ci, a.x * ci + a.y * cr };
+}
+// multiply by W_4 = -i (forward) / +i (reverse)
+template <bool REV> __device__ __forceinline__ float2 rot90(float2 a)
+{
+    return REV ? float2{ -a.y, a.x } : float2{ a.y, -a.x };
+}
+// multiply by W_16^e, e compile-time
+template <bool REV, int E> __device__ __forceinline__ float2 mul_w16(float2 a)
+{
+    if constexpr (E == 0)
+        return a;
+    else if constexpr (E == 1)
+        return cmulk<REV>(a, kC1, -kS1);
+    else if constexpr (E == 2) // h*(1 - i)
+        return REV ? float2{ kH * (a.x - a.y), kH * (a.x + a.y) } : float2{ kH * (a.x + a.y), kH * (a.y - a.x) };
+    else if constexpr (E == 3)
+        return cmulk<REV>(a, kS1, -kC1);
+    else if constexpr (E == 4)
+        return rot90<REV>(a);
+    else if constexpr (E == 6) // h*(-1 - i)
+        return REV ? float2{ -kH * (a.x + a.y), kH * (a.x - a.y) } : float2{ kH * (a.y - a.x), -kH * (a.x + a.y) };
+    else { // E == 9: -W_16^1
+        static_assert(E == 9, "unexpected W_16 exponent");
+        return cmulk<REV>(a, -kC1, kS1);
+    }
+}
+
+// in-place radix-4 DIF butterfly on elements at offsets 0, g, 2g, 3g: fft.h:342-345
+template <bool REV> __device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = rot90<REV>(b - d);
+    a = t0 + t2;
+    b = t1 + t3;
+    c = t0 - t2;
+    d = t1 - t3;
+}
+
+// Two consecutive radix-4 DIF stages on 16 registers; x[k] is the element at base + k*stride.
+// Stage X pairs k = j + 4r over r; its output twiddle W^(r*pos), pos = (thread part) + j*4*stride...
+// factors into w1[r-1] (thread part, general) times W_16^(r*j) (constant).  Stage Y pairs
+// k = 4r + r' over r' with output twiddle w2[r'-1] (general, absent in the last pass).
+template <bool REV, bool TW1, bool TW2>
+__device__ __forceinline__ void two_stages(float2 (&x)[16], const float2 (&w1)[3], const float2 (&w2)[3])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        bfly4<REV>(x[j], x[j + 4], x[j + 8], x[j + 12]);
+    // constants W_16^(r*j)
+    x[5] = mul_w16<REV, 1>(x[5]);
+    x[6] = mul_w16<REV, 2>(x[6]);
+    x[7] = mul_w16<REV, 3>(x[7]);
+    x[9] = mul_w16<REV, 2>(x[9]);
+    x[10] = mul_w16<REV, 4>(x[10]);
+    x[11] = mul_w16<REV, 6>(x[11]);
+    x[13] = mul_w16<REV, 3>(x[13]);
+    x[14] = mul_w16<REV, 6>(x[14]);
+    x[15] = mul_w16<REV, 9>(x[15]);
+    if constexpr (TW1) {
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                x[j + 4 * r] = cmul(x[j + 4 * r], w1[r - 1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        bfly4<REV>(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3]);
+        if constexpr (TW2) {
+            x[4 * r + 1] = cmul(x[4 * r + 1], w2[0]);
+            x[4 * r + 2] = cmul(x[4 * r + 2], w2[1]);
+            x[4 * r + 3] = cmul(x[4 * r + 3], w2[2]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t rev4bits(uint32_t v) // reverse the low 4 bits
+{
+    return __brev(v) >> 28;
+}
+
+// PREFETCH: fetch transform i+1 into registers during passes B/C of transform i (costs 32 VGPRs).
+// WAVES: occupancy the register allocator must leave room for (waves per SIMD = workgroups per CU).
+template <bool REV, bool PREFETCH, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__restrict__ data,
+                                                                  const float2 *__restrict__ tw,
+                                                                  uint64_t batch, float scale)
+{
+    // LDS slot of logical position p (8-byte units): p ^ (rev4bits(p >> 8) << 1)
+    __shared__ __attribute__((aligned(16))) float2 lds[4096];
+
+    const uint32_t t = threadIdx.x;
+
+    // ---- per-thread twiddles, identical for every transform: fetched once (fft.h:309 uses the
+    // same single row exp(-+2 pi i j / N) of the table)
+    float2 wA1[3], wA2[3], wB1[3], wB2[3];
+    const uint32_t rr = t & 15, b = t >> 4;
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        wA1[r - 1] = tw[r * t];        // W_4096^(r t)
+        wA2[r - 1] = tw[4 * r * t];    // W_1024^(r t)
+        wB1[r - 1] = tw[16 * r * rr];  // W_256^(r rr)
+        wB2[r - 1] = tw[64 * r * rr];  // W_64^(r rr)
+    }
+
+    // ---- LDS addressing (float2 units).  Loop-invariant address VECTORS are deliberately not kept
+    // in registers (they cost ~40 VGPRs): pass B uses two bases + immediate offsets, passes A and C
+    // rebuild theirs with one v_xor per access from a value the optimiser cannot hoist.
+    // pass A writes p = t + 256 k: slot 256 k + (t ^ (rev4bits(k) << 1))
+    // pass B (in place) p = 256 b + rr + 16 k: X = rev4bits(b) << 1 flips rr's bits 3..1 and k's bit 0,
+    //   i.e. slot b_base + 16 (k ^ b_flip) = (b_base +- 16 b_flip) + 16 k for even / odd k
+    const uint32_t xb = rev4bits(b) << 1;
+    const uint32_t b_base = 256 * b + (rr ^ (xb & 15));
+    const uint32_t b_flip = (xb >> 4) & 1;
+    float2 *const lds_b_even = lds + b_base + 16 * b_flip;
+    float2 *const lds_b_odd = lds + b_base - 16 * b_flip;
+    // pass C reads p = 16 m + k, m = digit_reverse4(t) so that outputs land at t + 256 j
+    const uint32_t m = ((t & 3) << 6) | (((t >> 2) & 3) << 4) | (((t >> 4) & 3) << 2) | (t >> 6);
+    const uint32_t xc = rev4bits(m >> 4) << 1;
+    const uint32_t c_base = 256 * (m >> 4) + 16 * ((m & 15) ^ (xc >> 4));
+    const uint32_t c_x = (xc >> 1) & 7; // pair index i -> i ^ c_x
+
+    float2 x[16], nx[PREFETCH ? 16 : 1];
+    uint64_t f = blockIdx.x;
+    if (PREFETCH && f < batch) {
+        const float2 *src = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = src[256 * k];
+    }
+    for (; f < batch; f += gridDim.x) {
+        if constexpr (!PREFETCH) {
+            const float2 *src = data + f * 4096 + t;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                x[k] = src[256 * k];
+        }
+        // ---- pass A: stages 0,1 (groups 1024, 256), fft.h:311-349 with i = 0,1
+        two_stages<REV, true, true>(x, wA1, wA2);
+        {
+            uint32_t ta = t;
+            asm volatile("" : "+v"(ta)); // keep the 16 xor'ed addresses out of loop-invariant registers
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                lds[256 * k + (ta ^ ((__brev((uint32_t)k) >> 28) << 1))] = x[k];
+        }
+        __syncthreads();
+
+        // prefetch the next transform; in flight during passes B and C
+        const uint64_t fn = f + gridDim.x;
+        if constexpr (PREFETCH) {
+            if (fn < batch) {
+                const float2 *src = data + fn * 4096 + t;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    nx[k] = src[256 * k];
+            }
+        }
+
+        // ---- pass B: stages 2,3 (groups 64, 16)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = (k & 1) ? lds_b_odd[16 * k] : lds_b_even[16 * k];
+        two_stages<REV, true, true>(x, wB1, wB2);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k & 1)
+                lds_b_odd[16 * k] = x[k];
+            else
+                lds_b_even[16 * k] = x[k];
+        }
+        __syncthreads();
+
+        // ---- pass C: stages 4,5 (groups 4, 1); only W_16 constants
+        {
+            uint32_t cx = c_x;
+            asm volatile("" : "+v"(cx));
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 v = *reinterpret_cast<const float4 *>(&lds[c_base + 2 * (i ^ cx)]);
+                x[2 * i] = float2{ v.x, v.y };
+                x[2 * i + 1] = float2{ v.z, v.w };
+            }
+        }
+        __syncthreads(); // every read of this transform is done: the tile may be overwritten
+        two_stages<REV, false, false>(x, wA1, wA2);
+
+        // ---- store; register k = 4 d1 + d0 holds X[t + 256 * (4 d0 + d1)]: fft.h:351-355 folded
+        float2 *dst = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float2 v = x[k];
+            if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+                v.x *= scale;
+                v.y *= scale;
+            }
+            dst[256 * (4 * (k & 3) + (k >> 2))] = v;
+        }
+        if constexpr (PREFETCH) {
+            if (fn < batch) {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    x[k] = nx[k];
+            }
+        }
+    }
+}
+
+int cu_count()
+{
+    static int cached = 0;
+    if (cached)
+        return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return 256;
+    cached = prop.multiProcessorCount;
+    return cached;
+}
+
+template <bool PREFETCH, int WAVES>
+void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s)
+{
+    float2 *d = reinterpret_cast<float2 *>(a.data);
+    const float2 *w = reinterpret_cast<const float2 *>(a.tw);
+    if (a.reverse)
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES>), dim3((uint32_t)grid), dim3(256), 0, s, d, w,
+                           a.batch, a.scale);
+    else
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES>), dim3((uint32_t)grid), dim3(256), 0, s, d, w,
+                           a.batch, a.scale);
+}
+} // namespace
+
+const char *fft4096_kernel_name(int variant)
+{
+    (void)variant;
+    return "sdsp_fft4096_r4_f32";
+}
+
+int fft4096_num_variants() { return 7; }
+
+// variants (all the same arithmetic; they differ in how HBM latency is hidden):
+//   0  persistent, register prefetch, 3 workgroups/CU      (default)
+//   1  persistent, register prefetch, 2 workgroups/CU
+//   2  persistent, register prefetch, 4 workgroups/CU (tight registers)
+//   3  persistent, no prefetch, 4 workgroups/CU
+//   4  persistent, no prefetch, 5 workgroups/CU
+//   5  one workgroup per transform, no prefetch, 4 workgroups/CU (hardware scheduling only)
+//   6  one workgroup per transform, no prefetch, 5 workgroups/CU
+int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    static const int per_cu[] = { 3, 2, 4, 4, 5, 0, 0 };
+    if (variant < 0 || variant >= fft4096_num_variants())
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown fft4096 variant");
+    uint64_t grid = per_cu[variant] ? (uint64_t)cu_count() * per_cu[variant] : a.batch;
+    if (grid > a.batch)
+        grid = a.batch;
+    if (grid > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (variant) {
+    case 0: launch_variant<true, 3>(a, grid, s); break;
+    case 1: launch_variant<true, 2>(a, grid, s); break;
+    case 2: launch_variant<true, 4>(a, grid, s); break;
+    case 3: launch_variant<false, 4>(a, grid, s); break;
+    case 4: launch_variant<false, 5>(a, grid, s); break;
+    case 5: launch_variant<false, 4>(a, grid, s); break;
+    default: launch_variant<false, 5>(a, grid, s); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft4096 launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+} // namespace sdsp_hip

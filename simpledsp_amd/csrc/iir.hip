@@ -1,0 +1,301 @@
+// iir.hip -- banks of cascaded second-order sections on gfx950.
+//
+// Batched form of sdsp::casc_2o_iir<m_t>::process (casc_2o_iir.h:36-80) and of the
+// numerator-folded casc_2o_iir_{lp,hp,bp}::process_spec (:286-295, :344-353, :402-411): many
+// independent channels, shared coefficients, per-channel state.  One lane owns one channel and
+// runs the reference's Direct-Form-I recurrence with the reference's operation order (this file
+// is compiled with -ffp-contract=off, so the f64 kernel reproduces the reference's doubles
+// bit for bit and block-by-block streaming is bit-identical to one long call).
+//
+// The path is HBM-bound (8 B per f32 sample, 33 flop): the work is in the data movement.  Each
+// channel's samples are contiguous in memory, so a lane reading "its" channel would touch one
+// cache line per lane.  Instead a wave moves a [64 channels x T samples] tile with 16-byte
+// per-lane accesses in which 128..256 consecutive bytes of one channel are covered by
+// neighbouring lanes, parks it in a padded (bank-conflict-free) LDS tile, and every lane then
+// reads its own row.  Results go back the same way.  The next tile's loads are issued before the
+// current tile is computed.  Coefficients live in SGPRs (kernel arguments).
+#include <hip/hip_runtime.h>
+
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+template <typename R, int M> struct iir_dev_args {
+    R *data;
+    R *state; // nullable; state[(3*j + age) * channels + c]
+    uint64_t channels, samples, stride;
+    R gain;
+    R a1[M], a2[M], b1[M], b2[M];
+};
+
+template <typename R> struct vec16;
+template <> struct vec16<float> { using type = float4; static constexpr int n = 4; };
+template <> struct vec16<double> { using type = double2; static constexpr int n = 2; };
+
+// One sample through the cascade.  y1[j] / y2[j] are level j's values one / two samples ago
+// (level 0 = gain-scaled input, level M = output): the reference's m_mem ring (casc_2o_iir.h:15)
+// with the ring index resolved at compile time.
+template <typename R, int KIND, int M>
+__device__ __forceinline__ R cascade_step(R x, const iir_dev_args<R, M> &p, R (&y1)[M + 1], R (&y2)[M + 1],
+                                          R (&y3)[M + 1])
+{
+    R cur[M + 1];
+    cur[0] = x * p.gain; // :52 / :242
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        R acc = cur[j];
+        if constexpr (KIND == SDSP_HIP_IIR_GENERIC) { // :67-68
+            acc += y1[j] * p.b1[j] - y1[j + 1] * p.a1[j];
+            acc += y2[j] * p.b2[j] - y2[j + 1] * p.a2[j];
+        } else if constexpr (KIND == SDSP_HIP_IIR_LP) { // :292-293
+            acc += y1[j] + y1[j] - y1[j + 1] * p.a1[j];
+            acc += y2[j] - y2[j + 1] * p.a2[j];
+        } else if constexpr (KIND == SDSP_HIP_IIR_HP) { // :350-351
+            acc += -y1[j] - y1[j] - y1[j + 1] * p.a1[j];
+            acc += y2[j] - y2[j + 1] * p.a2[j];
+        } else { // band pass :408-409
+            acc += -y1[j + 1] * p.a1[j];
+            acc += -y2[j] - y2[j + 1] * p.a2[j];
+        }
+        cur[j + 1] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j <= M; j++) {
+        y3[j] = y2[j];
+        y2[j] = y1[j];
+        y1[j] = cur[j];
+    }
+    return cur[M]; // :71 / :254
+}
+
+template <typename R, int M>
+__device__ __forceinline__ void load_state(const iir_dev_args<R, M> &p, uint64_t c, R (&y1)[M + 1],
+                                           R (&y2)[M + 1], R (&y3)[M + 1])
+{
+#pragma unroll
+    for (int j = 0; j <= M; j++) {
+        y1[j] = y2[j] = y3[j] = R(0);
+    }
+    if (p.state) {
+#pragma unroll
+        for (int j = 0; j <= M; j++) {
+            y1[j] = p.state[(uint64_t)(3 * j + 0) * p.channels + c];
+            y2[j] = p.state[(uint64_t)(3 * j + 1) * p.channels + c];
+            y3[j] = p.state[(uint64_t)(3 * j + 2) * p.channels + c];
+        }
+    }
+}
+
+template <typename R, int M>
+__device__ __forceinline__ void store_state(const iir_dev_args<R, M> &p, uint64_t c, const R (&y1)[M + 1],
+                                            const R (&y2)[M + 1], const R (&y3)[M + 1])
+{
+    if (p.state) {
+#pragma unroll
+        for (int j = 0; j <= M; j++) {
+            p.state[(uint64_t)(3 * j + 0) * p.channels + c] = y1[j];
+            p.state[(uint64_t)(3 * j + 1) * p.channels + c] = y2[j];
+            p.state[(uint64_t)(3 * j + 2) * p.channels + c] = y3[j];
+        }
+    }
+}
+
+// ---- direct variant: lane = channel, scalar global accesses.  Any alignment, any length.
+template <typename R, int KIND, int M>
+__global__ __launch_bounds__(256) void sdsp_iir_direct_kernel(iir_dev_args<R, M> p)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.channels)
+        return;
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, c, y1, y2, y3);
+    R *row = p.data + c * p.stride;
+    for (uint64_t s = 0; s < p.samples; s++)
+        row[s] = cascade_step<R, KIND, M>(row[s], p, y1, y2, y3);
+    store_state<R, M>(p, c, y1, y2, y3);
+}
+
+// ---- tiled variant.  ROWB = bytes of one channel covered per tile (T = ROWB / sizeof(R) samples).
+// Requirements (checked by the host): data 16-byte aligned, stride and samples multiples of 16 B.
+template <typename R, int KIND, int M, int ROWB>
+__global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> p)
+{
+    using V = typename vec16<R>::type;
+    constexpr int EPV = vec16<R>::n;             // elements per 16-byte vector
+    constexpr int T = ROWB / (int)sizeof(R);      // samples per tile row
+    constexpr int NV = ROWB / 16;                 // vectors per row == lanes per row
+    constexpr int RPI = 64 / NV;                  // rows covered by one wave-wide access
+    constexpr int PITCH = ROWB + 16;              // LDS row pitch in bytes (one vector of padding)
+    constexpr int WAVE_LDS = 64 * PITCH;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned char *tile = sdsp_iir_smem + wave * WAVE_LDS;
+
+    const uint64_t ch0 = ((uint64_t)blockIdx.x * 4 + wave) * 64;
+    const uint64_t my_ch = ch0 + lane;
+    const bool have_ch = my_ch < p.channels;
+
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, have_ch ? my_ch : 0, y1, y2, y3);
+
+    // cooperative access pattern: vector `piece` of row `i * RPI + sub`
+    const int piece = lane % NV;
+    const int sub = lane / NV;
+    const uint64_t n_tiles = (p.samples + T - 1) / T;
+
+    V stage[NV]; // NV == number of wave-wide accesses per tile (64 rows / RPI rows each)
+    auto issue_loads = [&](uint64_t t) {
+        const uint64_t s0 = t * T + (uint64_t)piece * EPV;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+            stage[i] = V{};
+            if (ch < p.channels && s0 < p.samples)
+                stage[i] = *reinterpret_cast<const V *>(p.data + ch * p.stride + s0);
+        }
+    };
+
+    if (n_tiles)
+        issue_loads(0);
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        // staged registers -> LDS tile
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+            *reinterpret_cast<V *>(tile + (i * RPI + sub) * PITCH + piece * 16) = stage[i];
+        __syncthreads();
+        if (t + 1 < n_tiles)
+            issue_loads(t + 1); // in flight while this tile is filtered
+
+        // every lane filters its own channel's T samples
+        const uint64_t left = p.samples - t * T;
+        const int valid = left < (uint64_t)T ? (int)left : T;
+        V *myrow = reinterpret_cast<V *>(tile + lane * PITCH);
+        if (valid == T) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                V x = myrow[v];
+                R *xe = reinterpret_cast<R *>(&x);
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                myrow[v] = x;
+            }
+        } else {
+            for (int v = 0; v * EPV < valid; v++) { // samples is a multiple of EPV
+                V x = myrow[v];
+                R *xe = reinterpret_cast<R *>(&x);
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                myrow[v] = x;
+            }
+        }
+        __syncthreads();
+
+        // LDS tile -> HBM with the cooperative pattern
+        const uint64_t s0 = t * T + (uint64_t)piece * EPV;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+            if (ch < p.channels && s0 < p.samples) {
+                const V v = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
+                *reinterpret_cast<V *>(p.data + ch * p.stride + s0) = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (have_ch && p.samples)
+        store_state<R, M>(p, my_ch, y1, y2, y3);
+}
+
+template <typename R, int M> iir_dev_args<R, M> make_args(const iir_args &a)
+{
+    iir_dev_args<R, M> p;
+    p.data = reinterpret_cast<R *>(a.data);
+    p.state = reinterpret_cast<R *>(a.state);
+    p.channels = a.channels;
+    p.samples = a.samples;
+    p.stride = a.stride;
+    p.gain = (R)a.gain;
+    for (int j = 0; j < M; j++) {
+        p.a1[j] = (R)a.a1[j];
+        p.a2[j] = (R)a.a2[j];
+        p.b1[j] = (R)a.b1[j];
+        p.b2[j] = (R)a.b2[j];
+    }
+    return p;
+}
+
+template <typename R, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
+{
+    const auto p = make_args<R, M>(a);
+    const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(R)) % 16 == 0) &&
+                         ((a.samples * sizeof(R)) % 16 == 0);
+    if (variant == 0 && !aligned)
+        variant = 3; // shapes the tiled kernel cannot address fall to the direct kernel
+    if (variant == 3) {
+        const uint64_t blocks = (a.channels + 255) / 256;
+        hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+    } else if (!aligned) {
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "tiled IIR variants need 16-byte aligned data/stride/samples");
+    } else {
+        const uint64_t blocks = (a.channels + 255) / 256;
+        if (variant == 0 || variant == 1) {
+            constexpr int ROWB = 128;
+            const size_t lds = 4 * 64 * (ROWB + 16);
+            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<R, KIND, M, ROWB>), dim3((uint32_t)blocks), dim3(256), lds,
+                               stream, p);
+        } else if (variant == 2) {
+            constexpr int ROWB = 256;
+            const size_t lds = 4 * 64 * (ROWB + 16);
+            auto kern = sdsp_iir_tiled_kernel<R, KIND, M, ROWB>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, stream, p);
+        } else {
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
+template <typename R, int KIND> int launch_k(const iir_args &a, int variant, hipStream_t stream)
+{
+    switch (a.sections) {
+    case 2: return launch_km<R, KIND, 2>(a, variant, stream);
+    case 4: return launch_km<R, KIND, 4>(a, variant, stream);
+    case 6: return launch_km<R, KIND, 6>(a, variant, stream);
+    case 8: return launch_km<R, KIND, 8>(a, variant, stream);
+    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be 2, 4, 6 or 8");
+    }
+}
+
+template <typename R> int launch_r(const iir_args &a, int variant, hipStream_t stream)
+{
+    switch (a.kind) {
+    case SDSP_HIP_IIR_GENERIC: return launch_k<R, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
+    case SDSP_HIP_IIR_LP: return launch_k<R, SDSP_HIP_IIR_LP>(a, variant, stream);
+    case SDSP_HIP_IIR_HP: return launch_k<R, SDSP_HIP_IIR_HP>(a, variant, stream);
+    case SDSP_HIP_IIR_BP: return launch_k<R, SDSP_HIP_IIR_BP>(a, variant, stream);
+    default: return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
+    }
+}
+} // namespace
+
+int launch_iir(int precision, const iir_args &a, int variant, void *stream)
+{
+    if (a.channels == 0 || a.samples == 0)
+        return SDSP_HIP_OK;
+    if ((a.channels + 255) / 256 > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return precision == SDSP_HIP_F64 ? launch_r<double>(a, variant, s) : launch_r<float>(a, variant, s);
+}
+} // namespace sdsp_hip

@@ -1,0 +1,79 @@
+// sdsp_hip_internal.h -- shared declarations of the libsdsp_hip implementation (not installed).
+#pragma once
+
+#include "sdsp_hip.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sdsp_hip
+{
+extern thread_local std::string g_last_error;
+int fail(int code, const std::string &msg);
+
+// host_math.cpp
+void make_twiddles(uint32_t n, int direction, std::vector<double> &out);
+int design_lp(uint32_t m, double f0, double fs, double gain_in, double *a, double *b, double *gain);
+int design_hp(uint32_t m, double f0, double fs, double gain_in, double *a, double *b, double *gain);
+int design_bp(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain);
+int preload(uint32_t m, int filter_type, const double *a, const double *b, double gain, double value,
+            double *mem);
+
+// ------------------------------------------------------------------------------------------
+// FFT: one "tile" launch = every workgroup transforms `cols` independent length-n sequences held
+// in LDS.  The same kernel serves contiguous batches (cols transforms per workgroup) and the two
+// HBM passes of the four-step decomposition for transforms larger than LDS.
+struct fft_tile_args {
+    const void *in;
+    void *out;
+    const void *tw;     // W_n^j, j in [0,n): direction already folded in (conjugated for reverse)
+    const void *tw_big; // four-step pass 1: W_N^j, j in [0,N) of the whole transform; else null
+    uint32_t n;         // sub-transform length held in LDS
+    uint32_t log2n;
+    uint32_t cols;      // sequences per workgroup
+    uint32_t pitch;     // LDS row pitch in complex elements (cols + padding)
+    uint64_t total_cols;       // sequences in the whole launch (ragged last tile is masked)
+    uint32_t tiles_per_group;  // tiles that make up one big transform (1 for contiguous batches)
+    uint64_t group_stride;     // elements between big transforms
+    uint64_t in_tile_step, out_tile_step;   // element offset between consecutive tiles of a group
+    uint64_t in_si, in_sc;     // input strides: sequence index i, column c
+    uint64_t out_sk, out_sc;   // output strides: frequency index k, column c
+    uint32_t in_c_fast, out_c_fast; // which index runs fastest over the lanes (coalescing)
+    uint32_t reverse;          // direction of the +-i rotation (twiddles are pre-conjugated)
+    uint32_t apply_scale;      // multiply by `scale` on store (reverse_fft::ScaleValues)
+    float scale;               // 1/N
+    double scale_d;
+};
+
+int launch_fft_tile(int precision, int radix, const fft_tile_args &a, uint64_t n_tiles, void *stream);
+size_t fft_tile_lds_bytes(int precision, uint32_t n, uint32_t pitch);
+size_t fft_tile_max_lds_bytes();
+
+// fast path: batched n = 4096, radix 4, f32 (BASELINE config 2 / 5)
+struct fft4096_args {
+    void *data;
+    const void *tw; // W_4096^j f32 complex
+    uint64_t batch;
+    float scale;
+    int reverse;
+};
+int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
+const char *fft4096_kernel_name(int variant);
+int fft4096_num_variants();
+
+// ------------------------------------------------------------------------------------------
+// IIR bank
+struct iir_args {
+    void *data;
+    void *state; // nullable
+    uint64_t channels, samples, stride;
+    uint32_t sections;
+    int kind;
+    // coefficients in double; kernels round to their precision
+    double gain;
+    double a1[SDSP_HIP_MAX_SECTIONS], a2[SDSP_HIP_MAX_SECTIONS];
+    double b1[SDSP_HIP_MAX_SECTIONS], b2[SDSP_HIP_MAX_SECTIONS];
+};
+int launch_iir(int precision, const iir_args &a, int variant, void *stream);
+} // namespace sdsp_hip

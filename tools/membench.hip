@@ -1,0 +1,103 @@
+// membench.hip -- in-place HBM streaming ceilings on MI355X for the access shapes the kernels use.
+// Not part of the product; used to decide between 16-byte and 8-byte per-lane global accesses and
+// to know what "100 %" of the achievable rate is for read+write-in-place traffic.
+//   hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o build/membench && build/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <typename V>
+__global__ __launch_bounds__(256) void copy_inplace(V *p, size_t n, float s)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        V v = p[i];
+        v.x *= s;
+        p[i] = v;
+    }
+}
+
+// the FFT-4096 shape: a 256-thread workgroup owns a 32 KiB transform; thread t touches
+// float2 elements t + 256 k, k < 16 (512 contiguous bytes per wave instruction)
+template <bool PREFETCH>
+__global__ __launch_bounds__(256) void fft_shape(float2 *p, size_t batch, float s)
+{
+    const unsigned t = threadIdx.x;
+    float2 x[16], nx[16];
+    size_t f = blockIdx.x;
+    if (PREFETCH && f < batch)
+        for (int k = 0; k < 16; k++) x[k] = p[f * 4096 + t + 256 * k];
+    for (; f < batch; f += gridDim.x) {
+        if (!PREFETCH)
+            for (int k = 0; k < 16; k++) x[k] = p[f * 4096 + t + 256 * k];
+        size_t fn = f + gridDim.x;
+        if (PREFETCH && fn < batch)
+            for (int k = 0; k < 16; k++) nx[k] = p[fn * 4096 + t + 256 * k];
+        for (int k = 0; k < 16; k++) { x[k].x *= s; p[f * 4096 + t + 256 * (4 * (k & 3) + (k >> 2))] = x[k]; }
+        if (PREFETCH && fn < batch)
+            for (int k = 0; k < 16; k++) x[k] = nx[k];
+    }
+}
+
+// same bytes with 16-byte lanes: thread t touches float4 (2 complex) at 2t + 512 k, k < 8
+__global__ __launch_bounds__(256) void fft_shape16(float4 *p, size_t batch, float s)
+{
+    const unsigned t = threadIdx.x;
+    float4 x[8];
+    for (size_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        for (int k = 0; k < 8; k++) x[k] = p[f * 2048 + t + 256 * k];
+        for (int k = 0; k < 8; k++) { x[k].x *= s; p[f * 2048 + t + 256 * k] = x[k]; }
+    }
+}
+
+template <typename F>
+double time_ms(F launch, int reps = 20)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) launch();
+    std::vector<float> ts;
+    for (int i = 0; i < reps; i++) {
+        CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+int main()
+{
+    const size_t bytes = 2ull << 30; // 65536 x 32 KiB = BASELINE config 2
+    void *d; CK(hipMalloc(&d, bytes)); CK(hipMemset(d, 0x3c, bytes));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d MHz, mem clock %d MHz, bus %d bit\n", prop.name, cus,
+           prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.memoryBusWidth);
+    auto report = [&](const char *name, double ms) {
+        printf("%-44s %8.3f ms  %8.1f GB/s (read+write)\n", name, ms, 2.0 * bytes / ms / 1e6);
+    };
+    for (int per_cu : {4, 8, 16}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "inplace float4 (16 B/lane), %d wg/CU", per_cu);
+        report(nm, time_ms([&] { copy_inplace<float4><<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
+        snprintf(nm, sizeof nm, "inplace float2 (8 B/lane), %d wg/CU", per_cu);
+        report(nm, time_ms([&] { copy_inplace<float2><<<cus * per_cu, 256>>>((float2 *)d, bytes / 8, 1.0f); }));
+    }
+    const size_t batch = bytes / 32768;
+    for (int per_cu : {2, 3, 4, 5, 8}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "fft shape float2 persistent, %d wg/CU", per_cu);
+        report(nm, time_ms([&] { fft_shape<false><<<cus * per_cu, 256>>>((float2 *)d, batch, 1.0f); }));
+        snprintf(nm, sizeof nm, "fft shape float2 persistent+prefetch, %d wg/CU", per_cu);
+        report(nm, time_ms([&] { fft_shape<true><<<cus * per_cu, 256>>>((float2 *)d, batch, 1.0f); }));
+        snprintf(nm, sizeof nm, "fft shape float4 persistent, %d wg/CU", per_cu);
+        report(nm, time_ms([&] { fft_shape16<<<cus * per_cu, 256>>>((float4 *)d, batch, 1.0f); }));
+    }
+    report("fft shape float2, one wg per transform", time_ms([&] { fft_shape<false><<<batch, 256>>>((float2 *)d, batch, 1.0f); }));
+    report("fft shape float4, one wg per transform", time_ms([&] { fft_shape16<<<batch, 256>>>((float4 *)d, batch, 1.0f); }));
+    CK(hipFree(d));
+    return 0;
+}
