@@ -5,6 +5,7 @@ The library is the product: if it cannot be loaded this module raises.  There is
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
@@ -81,6 +82,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  A process must end up
+    # with ONE HIP runtime: if torch is going to be used (it is our device-memory plumbing), it has
+    # to be loaded first so that this library binds to the same copy by soname.  Loading ours first
+    # leaves two HSA runtimes in the process and the second one finds no device.
+    if os.environ.get("SDSP_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not LIB_PATH.exists():
         if not build_if_missing:
             raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -m simpledsp_amd.build`")

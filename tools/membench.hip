@@ -53,6 +53,82 @@ __global__ __launch_bounds__(256) void fft_shape16(float4 *p, size_t batch, floa
     }
 }
 
+__global__ __launch_bounds__(256) void read_only(const float4 *p, size_t n, float *sink)
+{
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = p[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) *sink = acc;
+}
+__global__ __launch_bounds__(256) void write_only(float4 *p, size_t n, float s)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        p[i] = float4{ s, s, s, s };
+}
+__global__ __launch_bounds__(256) void copy_oop(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, float s)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = a[i];
+        v.x *= s;
+        b[i] = v;
+    }
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline float4 nt_load(const float4 *p) { v4f v = __builtin_nontemporal_load((const v4f *)p); return float4{ v.x, v.y, v.z, v.w }; }
+__device__ inline void nt_store(float4 a, float4 *p) { v4f v = { a.x, a.y, a.z, a.w }; __builtin_nontemporal_store(v, (v4f *)p); }
+__device__ inline float2 nt_load(const float2 *p) { v2f v = __builtin_nontemporal_load((const v2f *)p); return float2{ v.x, v.y }; }
+__device__ inline void nt_store(float2 a, float2 *p) { v2f v = { a.x, a.y }; __builtin_nontemporal_store(v, (v2f *)p); }
+__global__ __launch_bounds__(256) void copy_inplace_nt(float4 *p, size_t n, float s)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = nt_load(&p[i]);
+        v.x *= s;
+        nt_store(v, &p[i]);
+    }
+}
+__global__ __launch_bounds__(256) void copy_inplace_ntstore(float4 *p, size_t n, float s)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = p[i];
+        v.x *= s;
+        nt_store(v, &p[i]);
+    }
+}
+// every workgroup owns one contiguous chunk of the buffer (instead of grid-striding)
+__global__ __launch_bounds__(256) void copy_inplace_chunked(float4 *p, size_t n, float s)
+{
+    const size_t per = n / gridDim.x;
+    float4 *q = p + per * blockIdx.x;
+    for (size_t i = threadIdx.x; i < per; i += 256) {
+        float4 v = q[i];
+        v.x *= s;
+        q[i] = v;
+    }
+}
+// fft shape, out of place, with 4 transforms' loads in flight per workgroup
+__global__ __launch_bounds__(256) void fft_shape_oop(const float2 *__restrict__ a, float2 *__restrict__ b, size_t batch, float s)
+{
+    const unsigned t = threadIdx.x;
+    float2 x[16];
+    for (size_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        for (int k = 0; k < 16; k++) x[k] = a[f * 4096 + t + 256 * k];
+        for (int k = 0; k < 16; k++) { x[k].x *= s; b[f * 4096 + t + 256 * (4 * (k & 3) + (k >> 2))] = x[k]; }
+    }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void fft_shape_nt(float2 *p, size_t batch, float s)
+{
+    const unsigned t = threadIdx.x;
+    float2 x[16];
+    for (size_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        for (int k = 0; k < 16; k++) x[k] = NT ? nt_load(&p[f * 4096 + t + 256 * k]) : p[f * 4096 + t + 256 * k];
+        for (int k = 0; k < 16; k++) { x[k].x *= s; nt_store(x[k], &p[f * 4096 + t + 256 * (4 * (k & 3) + (k >> 2))]); }
+    }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 20)
 {
@@ -85,6 +161,34 @@ int main()
         report(nm, time_ms([&] { copy_inplace<float4><<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
         snprintf(nm, sizeof nm, "inplace float2 (8 B/lane), %d wg/CU", per_cu);
         report(nm, time_ms([&] { copy_inplace<float2><<<cus * per_cu, 256>>>((float2 *)d, bytes / 8, 1.0f); }));
+    }
+    {
+        void *d2; CK(hipMalloc(&d2, bytes)); CK(hipMemset(d2, 0x3c, bytes));
+        float *sink; CK(hipMalloc(&sink, 4));
+        auto rep1 = [&](const char *name, double ms) { printf("%-44s %8.3f ms  %8.1f GB/s (one direction)\n", name, ms, 1.0 * bytes / ms / 1e6); };
+        for (int per_cu : {4, 8, 16, 32}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "read only float4, %d wg/CU", per_cu);
+            rep1(nm, time_ms([&] { read_only<<<cus * per_cu, 256>>>((const float4 *)d, bytes / 16, sink); }));
+            snprintf(nm, sizeof nm, "write only float4, %d wg/CU", per_cu);
+            rep1(nm, time_ms([&] { write_only<<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
+            snprintf(nm, sizeof nm, "out-of-place copy float4, %d wg/CU", per_cu);
+            report(nm, time_ms([&] { copy_oop<<<cus * per_cu, 256>>>((const float4 *)d, (float4 *)d2, bytes / 16, 1.0f); }));
+            snprintf(nm, sizeof nm, "inplace float4 nt load+store, %d wg/CU", per_cu);
+            report(nm, time_ms([&] { copy_inplace_nt<<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
+            snprintf(nm, sizeof nm, "inplace float4 nt store only, %d wg/CU", per_cu);
+            report(nm, time_ms([&] { copy_inplace_ntstore<<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
+            snprintf(nm, sizeof nm, "inplace float4 chunked, %d wg/CU", per_cu);
+            report(nm, time_ms([&] { copy_inplace_chunked<<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
+        }
+        const size_t batch2 = bytes / 32768;
+        report("fft shape out-of-place, 4 wg/CU", time_ms([&] { fft_shape_oop<<<cus * 4, 256>>>((const float2 *)d, (float2 *)d2, batch2, 1.0f); }));
+        report("fft shape out-of-place, one wg/transform", time_ms([&] { fft_shape_oop<<<batch2, 256>>>((const float2 *)d, (float2 *)d2, batch2, 1.0f); }));
+        report("fft shape inplace nt store, 4 wg/CU", time_ms([&] { fft_shape_nt<false><<<cus * 4, 256>>>((float2 *)d, batch2, 1.0f); }));
+        report("fft shape inplace nt load+store, 4 wg/CU", time_ms([&] { fft_shape_nt<true><<<cus * 4, 256>>>((float2 *)d, batch2, 1.0f); }));
+        report("fft shape inplace nt store, one wg/transform", time_ms([&] { fft_shape_nt<false><<<batch2, 256>>>((float2 *)d, batch2, 1.0f); }));
+        report("fft shape inplace nt ld+st, one wg/transform", time_ms([&] { fft_shape_nt<true><<<batch2, 256>>>((float2 *)d, batch2, 1.0f); }));
+        CK(hipFree(d2)); CK(hipFree(sink));
     }
     const size_t batch = bytes / 32768;
     for (int per_cu : {2, 3, 4, 5, 8}) {
