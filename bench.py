@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64"])
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the per-GPU unit count")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
@@ -148,9 +148,9 @@ def cpu_baseline(workload: str, seconds: float):
             be.fft_inplace(bufs[0][:1].copy(), radix)  # build the plan outside the timed region
 
         def work(i):
-            a = bufs[i]
+            a = bufs[i].copy()
             while time.perf_counter() < deadline:
-                a[:] = bufs[i]  # fresh (finite) input each pass, as the reference BENCHMARK does (testFFT.cpp:243)
+                np.copyto(a, bufs[i])  # fresh (finite) input each pass, as the reference BENCHMARK does (testFFT.cpp:243)
                 be.fft_inplace(a, radix)
                 counts[i] += per
         unit = "FFT/s"
@@ -222,6 +222,15 @@ def main():
     mk = {"fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
           "iir64": lambda *a: make_iir(*a, f64=True)}[args.workload]
     step, units, unit_bytes, desc, metric, unit, dtype, keep = mk(sd, torch, dev, args)
+
+    # Setup, not measurement: wake the device up.  The first ~20 back-to-back launches after idle run
+    # up to 20 % slower (power/clock transient, profiles/r01_fft4096_summary.md); ~150 ms of untimed
+    # work here puts the W warmup steps and the K timed steps in steady state whatever W is.
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.15:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into tracked files:
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names trimmed)
+  profiles/<tag>_summary.md         bench line, per-kernel durations, PMC HBM traffic with the gfx950
+                                    FETCH_SIZE correction (MI355X_MICROARCH.md: FETCH_SIZE reads 1/2
+                                    of a wide coalesced stream; WRITE_SIZE is exact; both in KiB)
+  profiles/traffic.json             HBM bytes per launch per kernel, read by bench.py ("traffic")
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1]
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+out = ROOT / "profiles"
+out.mkdir(exist_ok=True)
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("sdsp_hip::(anonymous namespace)::", "")
+    name = re.sub(r"\(.*$", "", name)
+    return name[:120]
+
+
+def one(pattern):
+    g = glob.glob(str(src / pattern))
+    return g[0] if g else None
+
+
+lines = [f"# profile {tag}", ""]
+bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
+lines += ["## bench.py line (un-profiled run, same command)", "", "```json", json.dumps(bench, indent=1), "```", ""]
+
+stats = one("trace/*/*_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+with open(out / f"{tag}_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                    r["MaxNs"], r["StdDev"]])
+lines += ["## rocprofv3 --kernel-trace --stats (profiled run)", "",
+          "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+for r in rows:
+    lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
+                 f"{float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
+lines.append("")
+
+trace = one("trace/*/*_kernel_trace.csv")
+if trace:
+    t = [r for r in csv.DictReader(open(trace)) if "sdsp" in r["Kernel_Name"]]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in t]
+    lines += ["launch-by-launch durations of the sdsp kernels (us), in order:", "",
+              " ".join(f"{d:.0f}" for d in durs), ""]
+    if t:
+        r = t[0]
+        lines += [f"resources: VGPR {r.get('VGPR_Count')}, SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, "
+                  f"scratch {r.get('Scratch_Size')} B, workgroup {r.get('Workgroup_Size')}, grid {r.get('Grid_Size')}", ""]
+
+traffic = {}
+pm = defaultdict(lambda: defaultdict(list))
+for name in ("pmc_fetch", "pmc_write"):
+    p = one(f"{name}/*/*_counter_collection.csv")
+    if not p:
+        continue
+    for r in csv.DictReader(open(p)):
+        if "sdsp" in r["Kernel_Name"]:
+            pm[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines += ["## HBM traffic from PMC counters (separate --pmc passes)", "",
+          "| kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes/launch = (2*FETCH + WRITE)*1024 |", "|---|---|---|---|"]
+for k, c in pm.items():
+    f = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))
+    wv = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
+    b = (2 * f + wv) * 1024
+    traffic[k] = {"hbm_bytes_per_launch": b, "fetch_size_kib_raw": f, "write_size_kib": wv, "profile": tag}
+    lines.append(f"| `{k}` | {f:.1f} | {wv:.1f} | {b:.4g} |")
+alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
+if alg:
+    lines += ["", f"algorithmic bytes per launch: {alg} -> traffic / algorithmic = "
+              + ", ".join(f"{v['hbm_bytes_per_launch']/alg:.4f}" for v in traffic.values())]
+(out / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+
+tj = out / "traffic.json"
+allt = json.loads(tj.read_text()) if tj.exists() else {}
+for k, v in traffic.items():
+    allt[k.split("<")[0]] = v
+tj.write_text(json.dumps(allt, indent=1) + "\n")
+print((out / f"{tag}_summary.md").read_text())
