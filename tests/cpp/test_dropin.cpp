@@ -1,0 +1,426 @@
+// test_dropin.cpp -- the reference's own unit tests, restated without Catch2, compiled against THIS
+// repository's sdsp:: headers (include/sdsp/*.h -> C ABI -> HIP kernels on the MI355X).
+//
+// A user of simpledsp switches include paths and links libsdsp_hip.so; these are the checks the
+// reference ships (test/testFFT.cpp, test/testIIR.cpp -- cited per block) with the reference's own
+// tolerances, plus checks of the batched entries.  Usage: test_dropin <dir with the 9 impulse CSVs>
+// Exit code 0 = all passed, 1 = assertion failures, 3 = the GPU path is unavailable (no fallback).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <filesystem>
+#include <fstream>
+#include <limits>
+#include <random>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "sdsp/casc_2o_iir.h"
+#include "sdsp/fft.h"
+
+static int g_pass = 0, g_fail = 0;
+#define REQUIRE(cond)                                                                   \
+    do {                                                                                \
+        if (cond) {                                                                     \
+            ++g_pass;                                                                   \
+        } else {                                                                        \
+            ++g_fail;                                                                   \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);               \
+        }                                                                               \
+    } while (0)
+
+// testFFT.cpp:4-14
+template <size_t N> double calc_max_error(const sdsp::complex_array<N> &observed, const sdsp::complex_array<N> &expected)
+{
+    double worst = 0;
+    for (size_t i = 0; i < N; i++)
+        worst = std::max(worst, std::abs(observed[i] - expected[i]));
+    return worst;
+}
+
+// compile-time surface (fft.h:12-43, :217-236)
+static_assert(sdsp::log2(1024) == 10 && sdsp::log2(1) == 0 && sdsp::log4(4096) == 6, "log helpers");
+static_assert(sdsp::isPowerOf2(4096) && !sdsp::isPowerOf2(0) && !sdsp::isPowerOf2(96), "isPowerOf2");
+static_assert(sdsp::isPowerOf4(4096) && !sdsp::isPowerOf4(2048) && sdsp::isPowerOf4(1), "isPowerOf4");
+static_assert(sdsp::digit_reverse<64, 2>(1) == 32 && sdsp::digit_reverse<64, 4>(1) == 16, "digit_reverse");
+
+template <int RADIX, class T, size_t N> void run_fft(sdsp::complex_array<N> &a)
+{
+    if constexpr (RADIX == 2)
+        sdsp::fft_radix2<T>(a);
+    else
+        sdsp::fft_radix4<T>(a);
+}
+
+// testFFT.cpp:16-68 (radix 2) and :127-178 (radix 4)
+template <int RADIX> void test_fft_known_answers()
+{
+    constexpr sdsp::uint N{ 64 };
+    constexpr sdsp::uint n{ 7 };
+    const double tol = 4 * N * std::numeric_limits<double>::epsilon();
+    sdsp::complex_array<N> s{};
+    for (size_t i = 0; i < s.size(); i++)
+        s[i] = std::cos(n * 2 * M_PI * static_cast<double>(i) / N);
+    sdsp::complex_array<N> S{};
+    S[n] = N / 2;
+    S[N - n] = N / 2;
+    {
+        auto a = s;
+        run_fft<RADIX, sdsp::forward_fft>(a);
+        REQUIRE(calc_max_error(S, a) < tol);
+    }
+    {
+        auto A = S;
+        run_fft<RADIX, sdsp::reverse_fft>(A);
+        REQUIRE(calc_max_error(A, s) < tol);
+    }
+    {
+        sdsp::complex_array<N> s2{};
+        for (size_t i = 0; i < s2.size(); i++)
+            s2[i] = std::cos(n * 2 * M_PI * static_cast<double>(i) / N + (M_PI / 2.0));
+        run_fft<RADIX, sdsp::forward_fft>(s2);
+        sdsp::complex_array<N> S2{};
+        S2[n] = std::complex<double>(0, N / 2);
+        S2[N - n] = std::complex<double>(0, -(N / 2.0));
+        REQUIRE(calc_max_error(S2, s2) < tol);
+    }
+}
+
+// testFFT.cpp:70-125 / :180-235
+template <int RADIX> void test_fft_linearity()
+{
+    constexpr double freq1{ 1000.0 }, freq2{ 500.0 }, fs{ 8000.0 }, a1{ 1.5 }, a2{ 2.5 };
+    constexpr sdsp::uint N{ 256 };
+    sdsp::complex_array<N> x1{}, x2{}, mix{};
+    for (size_t i = 0; i < N; i++) {
+        x1[i] = std::sin(2.0 * M_PI * freq1 * (1.0 / fs) * static_cast<double>(i));
+        x2[i] = std::sin(2.0 * M_PI * freq2 * (1.0 / fs) * static_cast<double>(i));
+        mix[i] = a1 * x1[i] + a2 * x2[i];
+    }
+    run_fft<RADIX, sdsp::forward_fft>(mix);
+    run_fft<RADIX, sdsp::forward_fft>(x1);
+    run_fft<RADIX, sdsp::forward_fft>(x2);
+    sdsp::complex_array<N> sum{};
+    for (size_t i = 0; i < N; i++)
+        sum[i] = a1 * x1[i] + a2 * x2[i];
+    REQUIRE(calc_max_error(mix, sum) < 4 * N * std::numeric_limits<double>::epsilon());
+}
+
+// testFFT.cpp:237-256: the N=1024 benchmark body (BASELINE config 1) -- there it only has to run;
+// here the two radices must also agree with each other and satisfy Parseval
+void test_fft_benchmark_vector()
+{
+    sdsp::complex_array<1024> v{ 0.3535, 0.3535, 0.6464, 1.0607, 0.3535, -1.0607, -1.3535, -0.3535 };
+    auto r2 = v, r4 = v;
+    sdsp::fft_radix2(r2);
+    sdsp::fft_radix4(r4);
+    REQUIRE(calc_max_error(r2, r4) < 4 * 1024 * std::numeric_limits<double>::epsilon());
+    double e_t = 0, e_f = 0;
+    for (size_t i = 0; i < 1024; i++) {
+        e_t += std::norm(v[i]);
+        e_f += std::norm(r4[i]);
+    }
+    REQUIRE(std::abs(e_f / 1024 - e_t) < 1e-12);
+}
+
+void test_tables()
+{
+    const auto w = sdsp::calc_wCoeffs<64, sdsp::forward_fft>(); // fft.h:197-214
+    REQUIRE(w.size() == 6 && w[0][1] == std::complex<double>(-1.0, 0.0) && w[5][16] == std::complex<double>(0.0, -1.0));
+    const auto wr = sdsp::calc_wCoeffs<64, sdsp::reverse_fft>();
+    REQUIRE(wr[5][16] == std::complex<double>(0.0, 1.0) && wr[5][3] == std::conj(w[5][3]));
+    const auto c = sdsp::calc_trigs<64, sdsp::cosine_calculator>(); // fft.h:148-194
+    REQUIRE(c[5][16] == 0.0 && c[5][0] == 1.0 && c[5][32] == -1.0);
+    const auto lut = sdsp::calc_swap_lookup<64, 4>(); // fft.h:238-256: each pair listed once
+    size_t swaps = 0;
+    for (sdsp::uint i = 0; i < 64; i++)
+        if (lut[i] != i) {
+            ++swaps;
+            REQUIRE(lut[lut[i]] == lut[i]);
+        }
+    REQUIRE(swaps == 24); // 64 positions, 16 palindromes, 48/2 pairs
+}
+
+// testIIR.cpp:7-28
+std::tuple<std::vector<double>, sdsp::filter_type, double, double, double> csvreadImpulse2(const std::string &filename)
+{
+    std::ifstream myfile(filename);
+    unsigned int fType{ 0 }, n{ 0 };
+    char comma{ 0 };
+    double fs{ 0 }, f0{ 0 }, Q{ 0 };
+    myfile >> fType >> comma >> fs >> comma >> f0 >> comma >> Q >> comma >> n >> comma;
+    std::vector<double> impulse(n);
+    for (unsigned int i = 0; i + 1 < n; i++)
+        myfile >> impulse[i] >> comma;
+    myfile >> impulse.back();
+    return { impulse, static_cast<sdsp::filter_type>(fType), fs, f0, Q };
+}
+
+double max_abs_diff(const std::vector<double> &a, const std::vector<double> &b)
+{
+    double worst = 0;
+    for (size_t i = 0; i < a.size(); i++)
+        worst = std::max(worst, std::abs(a[i] - b[i]));
+    return worst;
+}
+
+template <class filter_t> void check_impulse_and_blocks(filter_t df, const std::vector<double> &readImpulse)
+{
+    filter_t df2 = df; // copy = coefficients and state (testIIR.cpp:48)
+    std::vector<double> data(readImpulse.size());
+    data[0] = 1.0;
+    df.process(data.begin(), data.end());
+    REQUIRE(max_abs_diff(data, readImpulse) < 1e-12); // testIIR.cpp:59
+
+    // the same stream in 32-sample blocks plus the tail must be identical (testIIR.cpp:61-75)
+    std::vector<double> data2(readImpulse.size());
+    data2[0] = 1.0;
+    constexpr unsigned int blockSize{ 32 };
+    unsigned int index{ 0 };
+    for (index = 0; index <= data2.size() - blockSize; index += blockSize)
+        df2.process(std::next(data2.begin(), index), std::next(data2.begin(), index + blockSize));
+    if (index < data2.size())
+        df2.process(std::next(data2.begin(), index), data2.end());
+    REQUIRE(data == data2);
+}
+
+// testIIR.cpp:30-77, :220-252, :301-333, :382-414
+void test_iir_impulse_responses(const std::string &path)
+{
+    size_t files = 0;
+    for (const auto &entry : std::filesystem::directory_iterator(path)) {
+        if (entry.path().extension() != ".csv")
+            continue;
+        ++files;
+        auto [readImpulse, fType, fs, f0, Q] = csvreadImpulse2(entry.path().string());
+        sdsp::casc_2o_iir<4> df;
+        if (fType == sdsp::filter_type::low_pass) {
+            df.set_lp_coeff(f0, fs);
+            sdsp::casc_2o_iir_lp<4> sp;
+            sp.set_lp_coeff(f0, fs);
+            check_impulse_and_blocks(sp, readImpulse);
+        } else if (fType == sdsp::filter_type::high_pass) {
+            df.set_hp_coeff(f0, fs);
+            sdsp::casc_2o_iir_hp<4> sp;
+            sp.set_hp_coeff(f0, fs);
+            check_impulse_and_blocks(sp, readImpulse);
+        } else if (fType == sdsp::filter_type::band_pass) {
+            df.set_bp_coeff(f0, fs, Q);
+            sdsp::casc_2o_iir_bp<4> sp;
+            sp.set_bp_coeff(f0, fs, Q);
+            check_impulse_and_blocks(sp, readImpulse);
+        } else {
+            REQUIRE(!"Unknown filter type");
+        }
+        check_impulse_and_blocks(df, readImpulse);
+    }
+    REQUIRE(files == 9);
+}
+
+// testIIR.cpp:79-171 (+ specialised twins :254-299, :335-380, :416-463)
+void test_iir_gain()
+{
+    constexpr double fs{ 100e3 }, f0{ 10e3 }, Q{ 1.1 };
+    auto run = [](auto &f1, auto &f2) {
+        std::array<double, 1024> impulse1{}, impulse2{};
+        impulse1[0] = impulse2[0] = 1.0;
+        f1.process(impulse1.begin(), impulse1.end());
+        f2.process(impulse2.begin(), impulse2.end());
+        double worst = 0;
+        for (size_t i = 0; i < impulse1.size(); i++)
+            worst = std::max(worst, std::abs(2.0 * impulse1[i] - impulse2[i]));
+        REQUIRE(worst < 1e-12);
+    };
+    {
+        sdsp::casc_2o_iir<4> a, b;
+        a.set_lp_coeff(f0, fs);
+        b.set_lp_coeff(f0, fs, 2.0);
+        run(a, b);
+    }
+    {
+        sdsp::casc_2o_iir<4> a, b;
+        a.set_hp_coeff(f0, fs);
+        b.set_hp_coeff(f0, fs, 2.0);
+        run(a, b);
+    }
+    {
+        sdsp::casc_2o_iir<4> a, b;
+        a.set_bp_coeff(f0, fs, Q);
+        b.set_bp_coeff(f0, fs, Q, 2.0);
+        run(a, b);
+    }
+    {
+        sdsp::casc_2o_iir_lp<4> a, b;
+        a.set_lp_coeff(f0, fs);
+        b.set_lp_coeff(f0, fs, 2.0);
+        run(a, b);
+    }
+    {
+        sdsp::casc_2o_iir_hp<4> a, b;
+        a.set_hp_coeff(f0, fs);
+        b.set_hp_coeff(f0, fs, 2.0);
+        run(a, b);
+    }
+    {
+        sdsp::casc_2o_iir_bp<4> a, b;
+        a.set_bp_coeff(f0, fs, Q);
+        b.set_bp_coeff(f0, fs, Q, 2.0);
+        run(a, b);
+    }
+}
+
+// testIIR.cpp:173-218
+void test_iir_preload()
+{
+    constexpr double fs{ 100e3 }, f0{ 10e3 }, Q{ 1.1 }, steadyValue{ 10.0 };
+    auto worst_dev = [](std::array<double, 1024> &d, double target) {
+        double worst = 0;
+        for (double v : d)
+            worst = std::max(worst, std::abs(v - target));
+        return worst;
+    };
+    {
+        std::array<double, 1024> steady;
+        steady.fill(steadyValue);
+        sdsp::casc_2o_iir<4> f;
+        f.set_lp_coeff(f0, fs);
+        f.preload_filter(steadyValue);
+        f.process(steady.begin(), steady.end());
+        REQUIRE(worst_dev(steady, steadyValue) < 1e-12);
+    }
+    {
+        std::array<double, 1024> steady;
+        steady.fill(steadyValue);
+        sdsp::casc_2o_iir<4> f;
+        f.set_hp_coeff(f0, fs);
+        f.preload_filter(steadyValue);
+        f.process(steady.begin(), steady.end());
+        REQUIRE(worst_dev(steady, 0.0) < 1e-12);
+    }
+    {
+        std::array<double, 1024> steady;
+        steady.fill(steadyValue);
+        sdsp::casc_2o_iir<4> f;
+        f.set_bp_coeff(f0, fs, Q);
+        f.preload_filter(steadyValue);
+        f.process(steady.begin(), steady.end());
+        REQUIRE(worst_dev(steady, 0.0) < 1e-12);
+    }
+}
+
+// testIIR.cpp:465-559: the benchmark bodies (4096-sample impulse, generic vs specialised) -- they
+// only have to run there; here generic and specialised must agree to the tests' 1e-12
+void test_iir_benchmark_bodies()
+{
+    constexpr double fs{ 100e3 }, f0{ 10e3 };
+    sdsp::casc_2o_iir<4> df;
+    df.set_lp_coeff(f0, fs);
+    sdsp::casc_2o_iir_lp<4> df2;
+    df2.set_lp_coeff(f0, fs);
+    sdsp::casc_2o_iir<4> other;
+    other.copy_coeff_from(df); // casc_2o_iir.h:28-34
+    std::array<double, 4096> a{}, b{}, c{};
+    a[0] = b[0] = c[0] = 1.0;
+    df.process(a.begin(), a.end());
+    df2.process(b.begin(), b.end());
+    other.process(c.begin(), c.end());
+    double worst = 0;
+    for (size_t i = 0; i < a.size(); i++)
+        worst = std::max(worst, std::abs(a[i] - b[i]));
+    REQUIRE(worst < 1e-12);
+    REQUIRE(a == c);
+}
+
+// the batched entries against the drop-in single-stream classes
+void test_batched_entries()
+{
+    std::mt19937_64 gen(0x5D5B);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    {
+        constexpr size_t N = 4096, B = 8;
+        std::vector<std::complex<float>> x(N * B);
+        for (auto &v : x)
+            v = { nd(gen), nd(gen) };
+        std::vector<std::complex<float>> y = x;
+        sdsp::fft_batch<sdsp::forward_fft>(4, y.data(), N, B);
+        double worst = 0;
+        for (size_t b = 0; b < B; b += 7) { // first and last transform through the f64 drop-in call
+            sdsp::complex_array<N> ref{};
+            for (size_t i = 0; i < N; i++)
+                ref[i] = std::complex<double>(x[b * N + i]);
+            sdsp::fft_radix4(ref);
+            double peak = 0, err = 0;
+            for (size_t i = 0; i < N; i++) {
+                peak = std::max(peak, std::abs(ref[i]));
+                err = std::max(err, std::abs(std::complex<double>(y[b * N + i]) - ref[i]));
+            }
+            worst = std::max(worst, err / peak);
+        }
+        REQUIRE(worst < 1e-6); // SURVEY 8(d) fp32 tolerance
+    }
+    {
+        constexpr size_t C = 70, S = 512;
+        std::vector<double> x(C * S);
+        for (auto &v : x)
+            v = static_cast<double>(nd(gen));
+        sdsp::casc_2o_iir_bank<4, double> bank(C);
+        bank.set_lp_coeff(10e3, 100e3);
+        std::vector<double> y = x;
+        bank.process_host(y.data(), S / 2); // two halves: state stays on the device
+        std::vector<double> second(C * (S / 2));
+        // second half of every channel is not contiguous in y: copy, filter, copy back
+        std::vector<double> firsthalf(C * (S / 2));
+        for (size_t c = 0; c < C; c++)
+            for (size_t s = 0; s < S / 2; s++)
+                firsthalf[c * (S / 2) + s] = x[c * S + s];
+        sdsp::casc_2o_iir_bank<4, double> bank2(C);
+        bank2.set_lp_coeff(10e3, 100e3);
+        bank2.process_host(firsthalf.data(), S / 2);
+        for (size_t c = 0; c < C; c++)
+            for (size_t s = 0; s < S / 2; s++)
+                second[c * (S / 2) + s] = x[c * S + S / 2 + s];
+        bank2.process_host(second.data(), S / 2);
+        sdsp::casc_2o_iir<4> one;
+        one.set_lp_coeff(10e3, 100e3);
+        std::vector<double> ch(x.begin() + 37 * S, x.begin() + 38 * S);
+        one.process(ch.begin(), ch.end());
+        bool same = true;
+        for (size_t s = 0; s < S / 2; s++)
+            same = same && firsthalf[37 * (S / 2) + s] == ch[s] && second[37 * (S / 2) + s] == ch[S / 2 + s];
+        REQUIRE(same); // f64 bank == single-stream class, bit for bit, across a block boundary
+        sdsp::casc_2o_iir_bank<4, float> fbank(C);
+        fbank.copy_coeff_from(bank2);
+        std::vector<float> xf(x.begin(), x.end());
+        fbank.process_host(xf.data(), S);
+        double peak = 0, err = 0;
+        for (size_t s = 0; s < S; s++) {
+            peak = std::max(peak, std::abs(ch[s]));
+            err = std::max(err, std::abs(static_cast<double>(xf[37 * S + s]) - ch[s]));
+        }
+        REQUIRE(err / peak < 1e-6);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const std::string csv_dir = argc > 1 ? argv[1] : "tests/golden/impulse_response";
+    try {
+        test_tables();
+        test_fft_known_answers<2>();
+        test_fft_known_answers<4>();
+        test_fft_linearity<2>();
+        test_fft_linearity<4>();
+        test_fft_benchmark_vector();
+        test_iir_impulse_responses(csv_dir);
+        test_iir_gain();
+        test_iir_preload();
+        test_iir_benchmark_bodies();
+        test_batched_entries();
+    } catch (const sdsp::hip_error &e) {
+        std::printf("GPU path unavailable (no CPU fallback): %s (code %d)\n", e.what(), e.code());
+        return 3;
+    }
+    std::printf("%d checks passed, %d failed\n", g_pass, g_fail);
+    return g_fail ? 1 : 0;
+}
