@@ -29,6 +29,7 @@ SOURCES = {
     "capi.hip": [],
     "fft_tile.hip": [],
     "fft4096.hip": [],
+    "fft1m.hip": [],
     "iir.hip": ["-ffp-contract=off"],
 }
 

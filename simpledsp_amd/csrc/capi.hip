@@ -58,7 +58,7 @@ int upload_twiddles(const std::vector<double> &w, int precision, void **dev)
     return SDSP_HIP_OK;
 }
 
-enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3 };
+enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4 };
 } // namespace
 
 struct sdsp_hip_fft_plan {
@@ -75,6 +75,7 @@ struct sdsp_hip_fft_plan {
     uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
     void *workspace = nullptr;
     uint64_t workspace_bytes = 0;
+    uint64_t ws_batch = 0;         // transforms the workspace holds (multi-pass paths run in slices)
     uint64_t twiddle_bytes = 0;
     void *host_stage = nullptr;    // device staging buffer of the *_host path
     uint64_t host_stage_bytes = 0;
@@ -141,13 +142,34 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_tile(p->precision, p->radix, a, tiles, stream);
     }
 
+    if (p->path == PATH_FFT1M && p->variant < 8) {
+        // chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache
+        // when pass 2 reads them (variant -> chunk size, for tuning)
+        static const uint64_t chunk_of[8] = { 16, 4, 8, 32, 2, 1, 12, 24 };
+        const uint64_t chunk = std::min<uint64_t>(chunk_of[p->variant], p->ws_batch);
+        const uint64_t N = 1ull << 20;
+        for (uint64_t done = 0; done < batch; done += chunk) {
+            fft1m_args a;
+            a.data = reinterpret_cast<char *>(data) + done * N * 8;
+            a.workspace = p->workspace;
+            a.tw_n = p->tw;
+            a.tw_1024 = p->tw1;
+            a.count = std::min<uint64_t>(chunk, batch - done);
+            a.scale = (float)(1.0 / (double)N);
+            a.reverse = rev;
+            if (int rc = launch_fft1m_r2_f32(a, stream))
+                return rc;
+        }
+        return SDSP_HIP_OK;
+    }
+
     // four-step: N = n1 x n2 viewed as a row-major [n1][n2] matrix (index n = n2_count*i1 + i2).
     //   pass 1: length-n1 transforms down the columns, times W_N^(i2*k1), data -> workspace
     //   pass 2: length-n2 transforms along the rows, written transposed, workspace -> data
     const uint64_t N = (uint64_t)p->n1 * p->n2;
     uint64_t done = 0;
     while (done < batch) {
-        const uint64_t nb = std::min<uint64_t>(p->max_batch, batch - done);
+        const uint64_t nb = std::min<uint64_t>(p->ws_batch, batch - done);
         char *d = reinterpret_cast<char *>(data) + done * N * esize(p->precision);
         fft_tile_args a{};
         a.in = d;
@@ -313,7 +335,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
     } else {
-        p->path = PATH_FOUR_STEP;
+        p->path = (n == (1u << 20) && radix == 2 && precision == SDSP_HIP_F32) ? PATH_FFT1M : PATH_FOUR_STEP;
         const uint32_t k = sdsp_hip_log2(n);
         if (radix == 2) {
             p->n1 = 1u << ((k + 1) / 2);
@@ -335,7 +357,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->twiddle_bytes = ((uint64_t)n + p->n1 + p->n2) * esize(precision);
         pick_tile(precision, p->n1, 16, &p->cols1, &p->pitch1);
         pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
-        p->workspace_bytes = p->max_batch * n * esize(precision);
+        // the tuned 2^20 path runs chunk by chunk and never needs more than 32 intermediate matrices
+        p->ws_batch = p->path == PATH_FFT1M ? std::min<uint64_t>(p->max_batch, 32) : p->max_batch;
+        p->workspace_bytes = p->ws_batch * n * esize(precision);
         if (!rc) {
             hipError_t e = hipMalloc(&p->workspace, p->workspace_bytes);
             if (e != hipSuccess)
@@ -453,13 +477,15 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->direction = p->direction;
     info->precision = p->precision;
     info->device = p->device;
-    info->hbm_passes = p->path == PATH_FOUR_STEP ? 2 : 1;
+    info->hbm_passes = (p->path == PATH_FOUR_STEP || p->path == PATH_FFT1M) ? 2 : 1;
     info->algorithmic_bytes = 2ull * p->n * esize(p->precision);
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;
     const char *name = "sdsp_fft_tile_kernel";
     if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants())
         name = fft4096_kernel_name(p->variant);
+    if (p->path == PATH_FFT1M && p->variant < 8)
+        name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

@@ -1,0 +1,331 @@
+// fft1m.hip -- batched N = 2^20 radix-2 complex f32 FFT for gfx950 (BASELINE config 3).
+//
+// sdsp::fft_radix2<T, 2^20> (fft.h:258-299) cannot even be compiled in the reference (its table
+// would be 320 MiB of constexpr data); here the 20 radix-2 butterfly stages run as a four-step
+// decomposition N = 1024 x 1024 with the transform viewed as a row-major [n1][n2] matrix:
+//
+//   pass 1 (sdsp_fft1m_cols)  for 16 adjacent columns n2: ten radix-2 stages over n1 (stride 1024),
+//                             times the inter-pass twiddle W_N^(n2*k1), written to the workspace
+//   pass 2 (sdsp_fft1m_rows)  for 16 adjacent rows k1: ten radix-2 stages over n2 (contiguous),
+//                             written transposed, X[k1 + 1024*k2], back into the caller's buffer
+//
+// Both passes use the same building block: 512 threads = 16 sequences x 32 threads, 32 points per
+// thread in registers, two register passes of five radix-2 DIF stages each, ONE exchange through
+// LDS.  The exchange moves the real and the imaginary plane separately, so a 1024 x 16 tile costs
+// 64 KiB instead of 128 KiB and two workgroups fit a CU (one loads while the other computes).
+// Twiddles: stage s of the first register pass needs W_1024^(2^s * u) for the thread's fixed u
+// (five values, fetched once) times compile-time W_32 constants; the second register pass needs
+// constants only.  Every global access is a 128-byte (pass 1, pass 2 stores) or 256-byte (pass 2
+// loads) contiguous segment.  LDS planes are XOR-swizzled so all ds_read/ds_write_b32 are
+// bank-conflict free.
+//
+// The host launches the two passes for a CHUNK of transforms at a time (see capi.hip) so that the
+// chunk's intermediate matrix is still resident in the 256 MiB Infinity Cache when pass 2 reads it:
+// HBM then sees little more than the compulsory 16 MiB per transform although the algorithm makes
+// two passes.  Streaming input / final output use non-temporal accesses to stay out of that cache;
+// the intermediate uses the default policy to stay in it.
+#include <hip/hip_runtime.h>
+
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 nt_load(const float2 *p)
+{
+    const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(p));
+    return float2{ v.x, v.y };
+}
+__device__ __forceinline__ void nt_store(float2 *p, float2 a)
+{
+    const v2f_t v = { a.x, a.y };
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f_t *>(p));
+}
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return float2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
+}
+
+// cos / sin of 2*pi*j/32, j < 16
+__device__ constexpr float kC32[16] = { 1.0f,
+                                        0.98078528040323044913f,
+                                        0.92387953251128675613f,
+                                        0.83146961230254523708f,
+                                        0.70710678118654752440f,
+                                        0.55557023301960222474f,
+                                        0.38268343236508977173f,
+                                        0.19509032201612826785f,
+                                        0.0f,
+                                        -0.19509032201612826785f,
+                                        -0.38268343236508977173f,
+                                        -0.55557023301960222474f,
+                                        -0.70710678118654752440f,
+                                        -0.83146961230254523708f,
+                                        -0.92387953251128675613f,
+                                        -0.98078528040323044913f };
+__device__ constexpr float kS32[16] = { 0.0f,
+                                        0.19509032201612826785f,
+                                        0.38268343236508977173f,
+                                        0.55557023301960222474f,
+                                        0.70710678118654752440f,
+                                        0.83146961230254523708f,
+                                        0.92387953251128675613f,
+                                        0.98078528040323044913f,
+                                        1.0f,
+                                        0.98078528040323044913f,
+                                        0.92387953251128675613f,
+                                        0.83146961230254523708f,
+                                        0.70710678118654752440f,
+                                        0.55557023301960222474f,
+                                        0.38268343236508977173f,
+                                        0.19509032201612826785f };
+
+// Five radix-2 DIF stages on 32 registers: x[k] is the element at base + k*stride.  Stage s pairs
+// (k, k + h), h = 16 >> s.  The lower output owes the twiddle W_{2H}^(pos mod H) (fft.h:286 applies
+// the same factor on the DIT side); it factors into the thread's w[s] (absent when TW is false) and
+// the compile-time constant W_32^((k mod h) << s).  After full unrolling e is a literal.
+template <bool REV, bool TW> __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 (&w)[5])
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int h = 16 >> s;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if ((k & h) != 0)
+                continue;
+            const float2 a = x[k], b = x[k + h];
+            x[k] = a + b;
+            float2 d = a - b;
+            const int e = (k & (h - 1)) << s; // W_32 exponent, 0..15
+            if (e == 8) {
+                d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x }; // -i / +i by swap and negate
+            } else if (e != 0) {
+                const float cr = kC32[e], ci = REV ? kS32[e] : -kS32[e];
+                d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
+            }
+            if constexpr (TW)
+                d = cmul(d, w[s]);
+            x[k + h] = d;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t brev5(uint32_t v) { return __brev(v) >> 27; }
+
+constexpr int kTile = 16;     // sequences per workgroup
+constexpr int kThreads = 512; // 16 sequences x 32 threads
+
+// ---- pass 1: 16 columns of one transform ------------------------------------------------------
+template <bool REV>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__restrict__ in,
+                                                               float2 *__restrict__ ws,
+                                                               const float2 *__restrict__ tw_n,    // W_N^j (j < 1024 used)
+                                                               const float2 *__restrict__ tw_1024, // W_1024^j
+                                                               uint32_t tiles_per_transform)
+{
+    // dynamic LDS (72 KiB > the 64 KiB static limit): one real plane [row][col] with rows pair-swapped
+    // by row bit 5, then W_1024^j staged in LDS because it is gathered 37x per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + 1024 * kTile * sizeof(float));
+    const uint32_t t = threadIdx.x;
+    const uint32_t c = t & 15, u = t >> 4;
+    reinterpret_cast<float4 *>(w1k)[t] = reinterpret_cast<const float4 *>(tw_1024)[t];
+    const uint32_t tile = blockIdx.x % tiles_per_transform;
+    const uint64_t xform = blockIdx.x / tiles_per_transform;
+    const uint32_t n2 = tile * kTile + c;
+    // addresses = wave-uniform base (SGPRs; the per-k part is a compile-time constant) + ONE 32-bit
+    // per-thread offset, so the 32 loads / stores share a single offset register
+    const float2 *src_tile = in + xform * (1ull << 20) + tile * kTile;
+    float2 *dst_tile = ws + xform * (1ull << 20) + tile * kTile;
+    const uint32_t toff = u * 1024 + c;
+
+    float2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = nt_load((src_tile + 32768 * k) + toff);
+
+    __syncthreads();
+    float2 w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++)
+        w[s] = w1k[u << s]; // W_1024^(2^s u)
+    fft32_dif<REV, true>(x, w); // stages with row strides 512 .. 32
+
+    // exchange rows {u + 32k} -> {32u + k}.  slot(row, col) = (row*16 + col) ^ (((row >> 5) & 1) << 4).
+    // Written with two base registers + compile-time offsets (per-element XOR'd addresses would
+    // cost 64 VGPRs): writes flip bit 4 for odd k; reads use slot 512u + c + 16*(k ^ (u&1)).
+    {
+        float *const w_even = plane + (u * 16 + c);
+        float *const w_odd = plane + ((u * 16 + c) ^ 16);
+        const int flip = (int)(u & 1) * 16;
+        const float *const r_even = plane + (512 * u + c) + flip;
+        const float *const r_odd = plane + (512 * u + c) - flip;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[512 * k] = x[k].x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k].x = ((k & 1) ? r_odd : r_even)[16 * k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[512 * k] = x[k].y;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k].y = ((k & 1) ? r_odd : r_even)[16 * k];
+    }
+    fft32_dif<REV, false>(x, w); // row strides 16 .. 1
+
+    // position 32u + k now holds Y[k1], k1 = bit_reverse10(32u + k); times W_N^(n2*k1), stored at
+    // row k1 of the intermediate matrix (default cache policy: it should stay in the Infinity Cache)
+    const uint32_t bu = brev5(u);
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0) // keep at most 8 elements' table fetches in flight (register budget)
+            __builtin_amdgcn_sched_barrier(0);
+        const uint32_t k1 = ((__brev((uint32_t)k) >> 27) << 5) | bu;
+        const uint32_t m = n2 * k1; // < 2^20
+        // W_N^m = W_1024^(m >> 10) * W_N^(m & 1023).  The coarse factor comes from the LDS table; the
+        // fine factor has an angle below 2*pi/1024 = 0.0062 rad, where cos = 1 - t^2/2 and
+        // sin = t - t^3/6 are exact to fp32 rounding (next terms < 6e-11): no second gather.
+        const float th = (float)(m & 1023) * 5.9921124526782858e-06f; // 2*pi / 2^20
+        const float th2 = th * th;
+        const float sn = th - th * th2 * 0.16666667f;
+        const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
+        const float2 tw = cmul(w1k[m >> 10], fine);
+        // default cache policy on purpose: a streaming (nt) store here measured 13 % slower overall,
+        // the intermediate is re-read from the Infinity Cache by pass 2
+        (dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27))[bu * 1024 + c] = cmul(x[k], tw);
+    }
+}
+
+// ---- pass 2: 16 rows of one transform, written transposed ------------------------------------------
+template <bool REV>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__restrict__ ws,
+                                                               float2 *__restrict__ out,
+                                                               const float2 *__restrict__ tw_1024,
+                                                               uint32_t tiles_per_transform, float scale)
+{
+    __shared__ float plane[kTile * 1024]; // [row][pos ^ (row | (((pos >> 5) & 1) << 4))]
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = blockIdx.x % tiles_per_transform;
+    const uint64_t xform = blockIdx.x / tiles_per_transform;
+
+    // first register pass: 32 lanes run along a row (256 contiguous bytes per half wave)
+    const uint32_t ra = t >> 5, ua = t & 31;
+    const float2 *src_tile = ws + xform * (1ull << 20) + (uint64_t)tile * kTile * 1024;
+    const uint32_t aoff = ra * 1024 + ua;
+    float2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = (src_tile + 32 * k)[aoff];
+    float2 w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++)
+        w[s] = tw_1024[ua << s];
+    fft32_dif<REV, true>(x, w);
+
+    // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
+    const uint32_t rb = t & 15, ub = t >> 4;
+    // write slot ra*1024 + ((ua + 32k) ^ (ra | ((k&1) << 4))): the XOR touches the low 5 bits only
+    //   -> bases (ua ^ ra) and (ua ^ ra ^ 16) + 32k;
+    // read slot rb*1024 + ((32ub + k) ^ (rb | ((ub&1) << 4))) = rb*1024 + 32ub + (k ^ rb ^ 16(ub&1)):
+    //   the register index is XOR'ed with a run-time value, so those 32 addresses are rebuilt from an
+    //   opaque value with one v_xor each instead of living in registers across the butterflies.
+    {
+        float *const w_even = plane + ra * 1024 + (ua ^ ra);
+        float *const w_odd = plane + ra * 1024 + (ua ^ ra ^ 16);
+        const float *const r_base = plane + rb * 1024 + 32 * ub;
+        const uint32_t rx = rb | ((ub & 1) << 4);
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[32 * k] = x[k].x;
+        __syncthreads();
+        {
+            uint32_t q = rx;
+            asm volatile("" : "+v"(q));
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                x[k].x = r_base[k ^ q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[32 * k] = x[k].y;
+        __syncthreads();
+        {
+            uint32_t q = rx;
+            asm volatile("" : "+v"(q));
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                x[k].y = r_base[k ^ q];
+        }
+    }
+    fft32_dif<REV, false>(x, w);
+
+    // position 32ub + k of row k1 holds X[k1 + 1024*k2], k2 = bit_reverse10(32ub + k): 16 lanes write
+    // 128 contiguous bytes.  Streaming (non-temporal) store of the final result.
+    float2 *dst_tile = out + xform * (1ull << 20) + tile * kTile;
+    const uint32_t bu = brev5(ub);
+    const uint32_t boff = bu * 1024 + rb;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        float2 v = x[k]; // k2 = bit_reverse5(k)*32 + bit_reverse5(ub)
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            v.x *= scale;
+            v.y *= scale;
+        }
+        nt_store((dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27)) + boff, v);
+    }
+}
+} // namespace
+
+// One chunk: `count` transforms, data -> workspace -> data.  The workspace holds `count` matrices.
+int launch_fft1m_r2_f32(const fft1m_args &a, void *stream)
+{
+    if (a.count == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t tiles = 1024 / kTile;
+    const uint64_t blocks = a.count * tiles;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
+    const float2 *in = reinterpret_cast<const float2 *>(a.data);
+    float2 *out = reinterpret_cast<float2 *>(a.data);
+    float2 *ws = reinterpret_cast<float2 *>(a.workspace);
+    const float2 *twn = reinterpret_cast<const float2 *>(a.tw_n);
+    const float2 *tw1k = reinterpret_cast<const float2 *>(a.tw_1024);
+    constexpr size_t kColsLds = 1024 * kTile * sizeof(float) + 1024 * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sdsp_fft1m_cols<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sdsp_fft1m_cols<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds);
+        attr_set = true;
+    }
+    if (a.reverse) {
+        hipLaunchKernelGGL(sdsp_fft1m_cols<true>, dim3((uint32_t)blocks), dim3(kThreads), kColsLds, s, in, ws, twn, tw1k, tiles);
+        hipLaunchKernelGGL(sdsp_fft1m_rows<true>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, ws, out, tw1k, tiles,
+                           a.scale);
+    } else {
+        hipLaunchKernelGGL(sdsp_fft1m_cols<false>, dim3((uint32_t)blocks), dim3(kThreads), kColsLds, s, in, ws, twn, tw1k, tiles);
+        hipLaunchKernelGGL(sdsp_fft1m_rows<false>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, ws, out, tw1k, tiles,
+                           a.scale);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft1m launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+} // namespace sdsp_hip

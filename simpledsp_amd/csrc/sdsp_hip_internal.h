@@ -62,6 +62,18 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
 const char *fft4096_kernel_name(int variant);
 int fft4096_num_variants();
 
+// fast path: batched n = 2^20, radix 2, f32 (BASELINE config 3), one chunk of transforms
+struct fft1m_args {
+    void *data;          // count x 2^20 complex, in place
+    void *workspace;     // count x 2^20 complex
+    const void *tw_n;    // W_N^j, j < 1024 used
+    const void *tw_1024; // W_1024^j
+    uint64_t count;
+    float scale;
+    int reverse;
+};
+int launch_fft1m_r2_f32(const fft1m_args &a, void *stream);
+
 // ------------------------------------------------------------------------------------------
 // IIR bank
 struct iir_args {
