@@ -116,7 +116,7 @@ def make_iir(sd, torch, dev, args, f64=False):
     desc = {
         "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place",
         "sections": 4, "channels_per_gpu": channels, "samples": samples,
-        "kernel": "sdsp_iir_tiled_kernel",
+        "kernel": "sdsp_iir_supertile_kernel",
     }
     unit_bytes = 16 if f64 else 8
     return step, channels * samples, unit_bytes, desc, "IIR samples/sec (4 cascaded biquads, LP)", "samples/s", "f64" if f64 else "f32", (bank, x)

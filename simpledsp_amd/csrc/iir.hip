@@ -31,8 +31,45 @@ template <typename R, int M> struct iir_dev_args {
 };
 
 template <typename R> struct vec16;
-template <> struct vec16<float> { using type = float4; static constexpr int n = 4; };
-template <> struct vec16<double> { using type = double2; static constexpr int n = 2; };
+template <> struct vec16<float> {
+    using type = float4;
+    using native = float __attribute__((ext_vector_type(4)));
+    static constexpr int n = 4;
+};
+template <> struct vec16<double> {
+    using type = double2;
+    using native = double __attribute__((ext_vector_type(2)));
+    static constexpr int n = 2;
+};
+
+// 16-byte global accesses; NT = streaming (non-temporal) policy: every sample is touched exactly
+// once each way, and keeping it out of the L2 / Infinity-Cache replacement state is worth ~10 % on
+// in-place streams (tools/membench.hip)
+template <typename R, bool NT> __device__ __forceinline__ typename vec16<R>::type gload16(const R *p)
+{
+    using V = typename vec16<R>::type;
+    using N = typename vec16<R>::native;
+    if constexpr (NT) {
+        const N v = __builtin_nontemporal_load(reinterpret_cast<const N *>(p));
+        V out;
+        __builtin_memcpy(&out, &v, 16);
+        return out;
+    } else {
+        return *reinterpret_cast<const V *>(p);
+    }
+}
+template <typename R, bool NT> __device__ __forceinline__ void gstore16(R *p, typename vec16<R>::type a)
+{
+    using V = typename vec16<R>::type;
+    using N = typename vec16<R>::native;
+    if constexpr (NT) {
+        N v;
+        __builtin_memcpy(&v, &a, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<N *>(p));
+    } else {
+        *reinterpret_cast<V *>(p) = a;
+    }
+}
 
 // One sample through the cascade.  y1[j] / y2[j] are level j's values one / two samples ago
 // (level 0 = gain-scaled input, level M = output): the reference's m_mem ring (casc_2o_iir.h:15)
@@ -119,7 +156,7 @@ __global__ __launch_bounds__(256) void sdsp_iir_direct_kernel(iir_dev_args<R, M>
 
 // ---- tiled variant.  ROWB = bytes of one channel covered per tile (T = ROWB / sizeof(R) samples).
 // Requirements (checked by the host): data 16-byte aligned, stride and samples multiples of 16 B.
-template <typename R, int KIND, int M, int ROWB>
+template <typename R, int KIND, int M, int ROWB, bool NT>
 __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> p)
 {
     using V = typename vec16<R>::type;
@@ -155,7 +192,7 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
             const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
             stage[i] = V{};
             if (ch < p.channels && s0 < p.samples)
-                stage[i] = *reinterpret_cast<const V *>(p.data + ch * p.stride + s0);
+                stage[i] = gload16<R, NT>(p.data + ch * p.stride + s0);
         }
     };
 
@@ -203,10 +240,108 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
             const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
             if (ch < p.channels && s0 < p.samples) {
                 const V v = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
-                *reinterpret_cast<V *>(p.data + ch * p.stride + s0) = v;
+                gstore16<R, NT>(p.data + ch * p.stride + s0, v);
             }
         }
         __syncthreads();
+    }
+    if (have_ch && p.samples)
+        store_state<R, M>(p, my_ch, y1, y2, y3);
+}
+
+// ---- super-tile variant (default).  One wave per workgroup owns 64 channels.  Per step it moves a
+// [64 channels x 512 bytes] super-tile: 32 sixteen-byte accesses per lane, issued ROW-GROUP-MAJOR --
+// the four consecutive 128-byte pieces of the same 8 channels in four back-to-back instructions -- so
+// that DRAM sees 512 contiguous bytes per channel per burst.  That shape streams at 5.66 TB/s in
+// place where one 128-byte piece per step stops at 4.9 (tools/membench.hip, gpurun_out round 1).
+// The super-tile stays in registers (128 VGPRs); its four 128-byte sub-tiles go through a padded
+// 9 KiB LDS transpose one after the other, and the filtered samples return to the same registers,
+// so the stores have the same burst shape as the loads.
+template <typename R, int KIND, int M, bool NT>
+__global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, M> p)
+{
+    using V = typename vec16<R>::type;
+    constexpr int EPV = vec16<R>::n;          // elements per 16-byte vector
+    constexpr int ROWB = 128;                 // bytes of one channel per sub-tile
+    constexpr int T = ROWB / (int)sizeof(R);  // samples per sub-tile
+    constexpr int NV = ROWB / 16;             // = 8 vectors per sub-row = lanes per row
+    constexpr int RPI = 64 / NV;              // = 8 rows per wave-wide access
+    constexpr int SUBS = 4;                   // sub-tiles per super-tile (512 B per channel)
+    constexpr int PITCH = ROWB + 16;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
+    unsigned char *tile = sdsp_iir_smem;
+    const int lane = threadIdx.x;
+    const uint64_t ch0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t my_ch = ch0 + lane;
+    const bool have_ch = my_ch < p.channels;
+
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, have_ch ? my_ch : 0, y1, y2, y3);
+
+    const int piece = lane % NV, sub = lane / NV;
+    const uint64_t n_super = (p.samples + SUBS * T - 1) / (SUBS * T);
+    for (uint64_t st = 0; st < n_super; st++) {
+        V stage[SUBS * NV]; // register 4*i + j: rows 8i..8i+7, sub-tile j
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+#pragma unroll
+            for (int j = 0; j < SUBS; j++) {
+                const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
+                stage[SUBS * i + j] = V{};
+                if (ch < p.channels && s0 < p.samples)
+                    stage[SUBS * i + j] = gload16<R, NT>(p.data + ch * p.stride + s0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SUBS; j++) {
+            const uint64_t first = (st * SUBS + j) * T;
+            if (first >= p.samples)
+                break;
+            const uint64_t left = p.samples - first;
+            const int valid = left < (uint64_t)T ? (int)left : T;
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                *reinterpret_cast<V *>(tile + (i * RPI + sub) * PITCH + piece * 16) = stage[SUBS * i + j];
+            __syncthreads();
+            V *myrow = reinterpret_cast<V *>(tile + lane * PITCH);
+            if (valid == T) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    V x = myrow[v];
+                    R *xe = reinterpret_cast<R *>(&x);
+#pragma unroll
+                    for (int e = 0; e < EPV; e++)
+                        xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                    myrow[v] = x;
+                }
+            } else {
+                for (int v = 0; v * EPV < valid; v++) {
+                    V x = myrow[v];
+                    R *xe = reinterpret_cast<R *>(&x);
+#pragma unroll
+                    for (int e = 0; e < EPV; e++)
+                        xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                    myrow[v] = x;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                stage[SUBS * i + j] = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+#pragma unroll
+            for (int j = 0; j < SUBS; j++) {
+                const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
+                if (ch < p.channels && s0 < p.samples)
+                    gstore16<R, NT>(p.data + ch * p.stride + s0, stage[SUBS * i + j]);
+            }
+        }
     }
     if (have_ch && p.samples)
         store_state<R, M>(p, my_ch, y1, y2, y3);
@@ -235,26 +370,38 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
     const auto p = make_args<R, M>(a);
     const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(R)) % 16 == 0) &&
                          ((a.samples * sizeof(R)) % 16 == 0);
-    if (variant == 0 && !aligned)
-        variant = 3; // shapes the tiled kernel cannot address fall to the direct kernel
+    // variants (identical arithmetic, bit-identical results):
+    //   0 super-tile (default)                 1 super-tile, streaming (non-temporal) accesses
+    //   2 tiled 128-byte rows, streaming       3 direct (any alignment)       4 tiled 256-byte rows
+    if (variant != 3 && !aligned)
+        variant = 3; // shapes the vector kernels cannot address fall to the direct kernel
     if (variant == 3) {
         const uint64_t blocks = (a.channels + 255) / 256;
         hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
-    } else if (!aligned) {
-        return fail(SDSP_HIP_ERR_INVALID_ARG, "tiled IIR variants need 16-byte aligned data/stride/samples");
+    } else if (variant == 0 || variant == 1) {
+        const uint64_t blocks = (a.channels + 63) / 64;
+        if (blocks > 0x7fffffffull)
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+        const size_t lds = 64 * (128 + 16);
+        if (variant == 0) // measured: default policy 5.12 TB/s vs streaming 5.03 TB/s (f32, round 1)
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false>), dim3((uint32_t)blocks), dim3(64), lds,
+                               stream, p);
+        else
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true>), dim3((uint32_t)blocks), dim3(64), lds,
+                               stream, p);
     } else {
         const uint64_t blocks = (a.channels + 255) / 256;
-        if (variant == 0 || variant == 1) {
+        if (variant == 2) {
             constexpr int ROWB = 128;
             const size_t lds = 4 * 64 * (ROWB + 16);
-            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<R, KIND, M, ROWB>), dim3((uint32_t)blocks), dim3(256), lds,
+            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<R, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds,
                                stream, p);
-        } else if (variant == 2) {
+        } else if (variant == 4) {
             constexpr int ROWB = 256;
             const size_t lds = 4 * 64 * (ROWB + 16);
-            auto kern = sdsp_iir_tiled_kernel<R, KIND, M, ROWB>;
+            auto kern = sdsp_iir_tiled_kernel<R, KIND, M, ROWB, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+                                      (int)lds);
             hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, stream, p);
         } else {
             return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");

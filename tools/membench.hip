@@ -129,6 +129,60 @@ __global__ __launch_bounds__(256) void fft_shape_nt(float2 *p, size_t batch, flo
     }
 }
 
+// the IIR bank's shape: a wave owns 64 rows (row pitch 16 KiB) and moves ROWB bytes of every row per
+// step; NT = non-temporal.  In place, no compute.
+template <int ROWB, bool NT>
+__global__ __launch_bounds__(256) void iir_shape(float4 *p, size_t rows, size_t row_vecs, float s)
+{
+    constexpr int NV = ROWB / 16, RPI = 64 / NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= rows) return;
+    const int piece = lane % NV, sub = lane / NV;
+    for (size_t t = 0; t < row_vecs / NV; t++) {
+        float4 v[NV];
+        for (int i = 0; i < NV; i++) {
+            float4 *q = p + (r0 + i * RPI + sub) * row_vecs + t * NV + piece;
+            v[i] = NT ? nt_load(q) : *q;
+        }
+        for (int i = 0; i < NV; i++) {
+            float4 *q = p + (r0 + i * RPI + sub) * row_vecs + t * NV + piece;
+            v[i].x *= s;
+            if (NT) nt_store(v[i], q); else *q = v[i];
+        }
+    }
+}
+
+// as iir_shape<128> (one instruction = 8 rows x 128 B) but a super-tile of 512 B per row is fetched
+// with the row's four 128-byte pieces in four BACK-TO-BACK instructions (row-group-major order),
+// 32 loads then 32 stores per wave.  One wave per workgroup.
+template <bool NT>
+__global__ __launch_bounds__(64) void iir_shape_rg(float4 *p, size_t rows, size_t row_vecs, float s)
+{
+    const int lane = threadIdx.x;
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    if (r0 >= rows) return;
+    const int piece = lane % 8, sub = lane / 8;
+    for (size_t t = 0; t < row_vecs / 32; t++) {
+        float4 v[32];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float4 *q = p + (r0 + i * 8 + sub) * row_vecs + t * 32 + j * 8 + piece;
+                v[4 * i + j] = NT ? nt_load(q) : *q;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float4 *q = p + (r0 + i * 8 + sub) * row_vecs + t * 32 + j * 8 + piece;
+                v[4 * i + j].x *= s;
+                if (NT) nt_store(v[4 * i + j], q); else *q = v[4 * i + j];
+            }
+    }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 20)
 {
@@ -155,7 +209,7 @@ int main()
     auto report = [&](const char *name, double ms) {
         printf("%-44s %8.3f ms  %8.1f GB/s (read+write)\n", name, ms, 2.0 * bytes / ms / 1e6);
     };
-    for (int per_cu : {4, 8, 16}) {
+    for (int per_cu : {4}) {
         char nm[96];
         snprintf(nm, sizeof nm, "inplace float4 (16 B/lane), %d wg/CU", per_cu);
         report(nm, time_ms([&] { copy_inplace<float4><<<cus * per_cu, 256>>>((float4 *)d, bytes / 16, 1.0f); }));
@@ -166,7 +220,7 @@ int main()
         void *d2; CK(hipMalloc(&d2, bytes)); CK(hipMemset(d2, 0x3c, bytes));
         float *sink; CK(hipMalloc(&sink, 4));
         auto rep1 = [&](const char *name, double ms) { printf("%-44s %8.3f ms  %8.1f GB/s (one direction)\n", name, ms, 1.0 * bytes / ms / 1e6); };
-        for (int per_cu : {4, 8, 16, 32}) {
+        for (int per_cu : {4}) {
             char nm[96];
             snprintf(nm, sizeof nm, "read only float4, %d wg/CU", per_cu);
             rep1(nm, time_ms([&] { read_only<<<cus * per_cu, 256>>>((const float4 *)d, bytes / 16, sink); }));
@@ -190,8 +244,23 @@ int main()
         report("fft shape inplace nt ld+st, one wg/transform", time_ms([&] { fft_shape_nt<true><<<batch2, 256>>>((float2 *)d, batch2, 1.0f); }));
         CK(hipFree(d2)); CK(hipFree(sink));
     }
+    {
+        // 131072 rows x 16 KiB = 2 GiB, 512 workgroups of 4 waves
+        const size_t rows = bytes / 16384, row_vecs = 1024;
+        const int blocks = (int)(rows / 256);
+        report("iir shape 128 B/row/step, plain", time_ms([&] { iir_shape<128, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 128 B/row/step, nt", time_ms([&] { iir_shape<128, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 256 B/row/step, plain", time_ms([&] { iir_shape<256, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 256 B/row/step, nt", time_ms([&] { iir_shape<256, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 512 B/row/step, plain", time_ms([&] { iir_shape<512, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 512 B/row/step, nt", time_ms([&] { iir_shape<512, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 4x128 B back-to-back, 1-wave wg, plain", time_ms([&] { iir_shape_rg<false><<<(int)(rows / 64), 64>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 4x128 B back-to-back, 1-wave wg, nt", time_ms([&] { iir_shape_rg<true><<<(int)(rows / 64), 64>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 1024 B/row/step, plain", time_ms([&] { iir_shape<1024, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        report("iir shape 1024 B/row/step, nt", time_ms([&] { iir_shape<1024, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+    }
     const size_t batch = bytes / 32768;
-    for (int per_cu : {2, 3, 4, 5, 8}) {
+    for (int per_cu : {3}) {
         char nm[96];
         snprintf(nm, sizeof nm, "fft shape float2 persistent, %d wg/CU", per_cu);
         report(nm, time_ms([&] { fft_shape<false><<<cus * per_cu, 256>>>((float2 *)d, batch, 1.0f); }));
