@@ -232,28 +232,22 @@ def main():
             step()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    # W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides,
+    # max over ranks (simpledsp_amd/dist.py); HIP events on the launch stream give the kernel time.
+    from simpledsp_amd.dist import timed_steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
+    n_calls = {"i": 0}
+
+    def timed_step():
+        if n_calls["i"] == args.warmup:
+            ev0.record()
         step()
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # HIP events on the launch stream
-    if dist:
-        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+        n_calls["i"] += 1
+        if n_calls["i"] == args.warmup + args.steps:
+            ev1.record()
+
+    wall = timed_steps(timed_step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), dist, dev)
+    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)
 
     if rank == 0:
         total_units = units * world * args.steps
