@@ -131,7 +131,8 @@ def cpu_baseline(workload: str, seconds: float):
         from oracle import Oracle, Reference
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "", "cores": 0, "kind": "port", "sample": f"oracle unavailable: {e}"}
-    kind = "reference" if Reference.available() else "port"
+    # the reference cannot be compiled for N = 2^20: that workload is timed on the port
+    kind = "reference" if (Reference.available() and workload != "fft1m") else "port"
     be = Reference() if kind == "reference" else Oracle()
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
     rng = np.random.default_rng(0x5D5B)
@@ -139,9 +140,9 @@ def cpu_baseline(workload: str, seconds: float):
     counts = [0] * cores
 
     if workload.startswith("fft"):
-        n, radix, per = (4096, 4, 64) if workload == "fft4096" else (4096, 2, 64)
-        if workload == "fft1m" and kind == "port":
-            n, radix, per = 1 << 20, 2, 1
+        n, radix, per = (4096, 4, 64) if workload == "fft4096" else (1 << 20, 2, 1)
+        if workload == "fft1m":
+            cores = min(cores, 8)  # 320 MiB of tables + 16 MiB per thread
         bufs = [(rng.standard_normal((per, n)) + 1j * rng.standard_normal((per, n))).astype(np.complex128)
                 for _ in range(cores)]
         if kind == "port":
@@ -185,17 +186,18 @@ def cpu_baseline(workload: str, seconds: float):
             "sample": sample + f"; {cores} threads, float64 (the reference's precision)"}
 
 
-def read_traffic(kernel_prefix: str):
-    """HBM bytes per launch from a committed PMC summary (profiles/traffic.json), or None."""
+def read_traffic(kernels: str):
+    """HBM bytes per step from the committed PMC summary (profiles/traffic.json), or None.
+    `kernels` may name several kernels joined by '+' (multi-pass paths): their traffic is summed."""
     p = ROOT / "profiles" / "traffic.json"
     try:
         t = json.loads(p.read_text())
-        for k, v in t.items():
-            if kernel_prefix.startswith(k) or k.startswith(kernel_prefix):
-                return v.get("hbm_bytes_per_launch")
+        total = 0.0
+        for name in kernels.split("+"):
+            total += t[name]["hbm_bytes_per_launch"] * t[name].get("launches_per_step", 1)
+        return total
     except Exception:
-        pass
-    return None
+        return None
 
 
 def main():

@@ -81,6 +81,11 @@ for k, c in pm.items():
     b = (2 * f + wv) * 1024
     traffic[k] = {"hbm_bytes_per_launch": b, "fetch_size_kib_raw": f, "write_size_kib": wv, "profile": tag}
     lines.append(f"| `{k}` | {f:.1f} | {wv:.1f} | {b:.4g} |")
+# launches of each kernel per bench step: 1, except the chunked N=2^20 path (256 transforms per step
+# in chunks of 16 -> 16 launches of each pass, csrc/capi.hip)
+LAUNCHES_PER_STEP = {"sdsp_fft1m_cols": 16, "sdsp_fft1m_rows": 16}
+for k in traffic:
+    traffic[k]["launches_per_step"] = LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
 alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
 if alg:
     lines += ["", f"algorithmic bytes per launch: {alg} -> traffic / algorithmic = "
@@ -89,7 +94,14 @@ if alg:
 
 tj = out / "traffic.json"
 allt = json.loads(tj.read_text()) if tj.exists() else {}
+# key by bare kernel name; forward/reverse instantiations of one template are averaged
+merged = {}
 for k, v in traffic.items():
-    allt[k.split("<")[0]] = v
+    merged.setdefault(k.split("<")[0], []).append(v)
+for k, vs in merged.items():
+    allt[k] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in vs) / len(vs),
+               "fetch_size_kib_raw": sum(v["fetch_size_kib_raw"] for v in vs) / len(vs),
+               "write_size_kib": sum(v["write_size_kib"] for v in vs) / len(vs),
+               "launches_per_step": vs[0]["launches_per_step"], "profile": tag}
 tj.write_text(json.dumps(allt, indent=1) + "\n")
 print((out / f"{tag}_summary.md").read_text())
