@@ -44,6 +44,16 @@ __device__ __forceinline__ void nt_store(float2 *p, float2 a)
     const v2f_t v = { a.x, a.y };
     __builtin_nontemporal_store(v, reinterpret_cast<v2f_t *>(p));
 }
+// uniform base (SGPR pair) + 32-bit per-thread byte offset: the global_load/store "saddr" form, one
+// VGPR of address instead of a 64-bit pair per access
+__device__ __forceinline__ const float2 *at(const float2 *base, uint32_t byte_off)
+{
+    return reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float2 *at(float2 *base, uint32_t byte_off)
+{
+    return reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off);
+}
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
@@ -89,11 +99,16 @@ __device__ constexpr float kS32[16] = { 0.0f,
 // (k, k + h), h = 16 >> s.  The lower output owes the twiddle W_{2H}^(pos mod H) (fft.h:286 applies
 // the same factor on the DIT side); it factors into the thread's w[s] (absent when TW is false) and
 // the compile-time constant W_32^((k mod h) << s).  After full unrolling e is a literal.
-template <bool REV, bool TW> __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 (&w)[5])
+// `wsrc` is the table W_1024^j (LDS or global) and `u` the thread's index: stage s fetches its
+// thread twiddle W_1024^(u << s) when the stage starts, so it does not occupy registers earlier.
+template <bool REV, bool TW> __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, uint32_t u)
 {
 #pragma unroll
     for (int s = 0; s < 5; s++) {
         const int h = 16 >> s;
+        float2 ws = float2{ 1.0f, 0.0f };
+        if constexpr (TW)
+            ws = wsrc[u << s];
 #pragma unroll
         for (int k = 0; k < 32; k++) {
             if ((k & h) != 0)
@@ -109,7 +124,7 @@ template <bool REV, bool TW> __device__ __forceinline__ void fft32_dif(float2 (&
                 d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
             }
             if constexpr (TW)
-                d = cmul(d, w[s]);
+                d = cmul(d, ws);
             x[k + h] = d;
         }
     }
@@ -143,19 +158,15 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
     // per-thread offset, so the 32 loads / stores share a single offset register
     const float2 *src_tile = in + xform * (1ull << 20) + tile * kTile;
     float2 *dst_tile = ws + xform * (1ull << 20) + tile * kTile;
-    const uint32_t toff = u * 1024 + c;
+    const uint32_t toff = (u * 1024 + c) * 8u; // bytes
 
     float2 x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
-        x[k] = nt_load((src_tile + 32768 * k) + toff);
+        x[k] = nt_load(at(src_tile + 32768 * k, toff));
 
     __syncthreads();
-    float2 w[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++)
-        w[s] = w1k[u << s]; // W_1024^(2^s u)
-    fft32_dif<REV, true>(x, w); // stages with row strides 512 .. 32
+    fft32_dif<REV, true>(x, w1k, u); // stages with row strides 512 .. 32; twiddles W_1024^(2^s u)
 
     // exchange rows {u + 32k} -> {32u + k}.  slot(row, col) = (row*16 + col) ^ (((row >> 5) & 1) << 4).
     // Written with two base registers + compile-time offsets (per-element XOR'd addresses would
@@ -182,11 +193,12 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
         for (int k = 0; k < 32; k++)
             x[k].y = ((k & 1) ? r_odd : r_even)[16 * k];
     }
-    fft32_dif<REV, false>(x, w); // row strides 16 .. 1
+    fft32_dif<REV, false>(x, w1k, u); // row strides 16 .. 1
 
     // position 32u + k now holds Y[k1], k1 = bit_reverse10(32u + k); times W_N^(n2*k1), stored at
     // row k1 of the intermediate matrix (default cache policy: it should stay in the Infinity Cache)
     const uint32_t bu = brev5(u);
+    const uint32_t soff = (bu * 1024 + c) * 8u; // bytes
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0) // keep at most 8 elements' table fetches in flight (register budget)
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
         const float2 tw = cmul(w1k[m >> 10], fine);
         // default cache policy on purpose: a streaming (nt) store here measured 13 % slower overall,
         // the intermediate is re-read from the Infinity Cache by pass 2
-        (dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27))[bu * 1024 + c] = cmul(x[k], tw);
+        *at(dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27), soff) = cmul(x[k], tw);
     }
 }
 
@@ -222,16 +234,12 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
     // first register pass: 32 lanes run along a row (256 contiguous bytes per half wave)
     const uint32_t ra = t >> 5, ua = t & 31;
     const float2 *src_tile = ws + xform * (1ull << 20) + (uint64_t)tile * kTile * 1024;
-    const uint32_t aoff = ra * 1024 + ua;
+    const uint32_t aoff = (ra * 1024 + ua) * 8u; // bytes
     float2 x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
-        x[k] = (src_tile + 32 * k)[aoff];
-    float2 w[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++)
-        w[s] = tw_1024[ua << s];
-    fft32_dif<REV, true>(x, w);
+        x[k] = *at(src_tile + 32 * k, aoff);
+    fft32_dif<REV, true>(x, tw_1024, ua);
 
     // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
     const uint32_t rb = t & 15, ub = t >> 4;
@@ -269,13 +277,13 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
                 x[k].y = r_base[k ^ q];
         }
     }
-    fft32_dif<REV, false>(x, w);
+    fft32_dif<REV, false>(x, tw_1024, ua);
 
     // position 32ub + k of row k1 holds X[k1 + 1024*k2], k2 = bit_reverse10(32ub + k): 16 lanes write
     // 128 contiguous bytes.  Streaming (non-temporal) store of the final result.
     float2 *dst_tile = out + xform * (1ull << 20) + tile * kTile;
     const uint32_t bu = brev5(ub);
-    const uint32_t boff = bu * 1024 + rb;
+    const uint32_t boff = (bu * 1024 + rb) * 8u; // bytes
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0)
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
             v.x *= scale;
             v.y *= scale;
         }
-        nt_store((dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27)) + boff, v);
+        nt_store(at(dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27), boff), v);
     }
 }
 } // namespace
