@@ -30,6 +30,7 @@ SOURCES = {
     "fft_tile.hip": [],
     "fft4096.hip": [],
     "fft1m.hip": [],
+    "fft_reg.hip": [],
     "iir.hip": ["-ffp-contract=off"],
 }
 

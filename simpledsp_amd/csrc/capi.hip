@@ -58,7 +58,7 @@ int upload_twiddles(const std::vector<double> &w, int precision, void **dev)
     return SDSP_HIP_OK;
 }
 
-enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4 };
+enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
 struct sdsp_hip_fft_plan {
@@ -117,7 +117,20 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r4_f32(a, p->variant, stream);
     }
 
-    if (p->path == PATH_TILE || p->path == PATH_FFT4096) {
+    if (p->path == PATH_REG && p->variant < 2) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = rev;
+        a.nontemporal = p->variant == 0;
+        return launch_fft_reg_f32(a, stream);
+    }
+
+    if (p->path == PATH_TILE || p->path == PATH_FFT4096 || p->path == PATH_REG) {
         fft_tile_args a{};
         a.in = data;
         a.out = data;
@@ -327,7 +340,12 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     if (n == 1) {
         p->path = PATH_NOOP;
     } else if (n <= lds_cap_n) {
-        p->path = (n == 4096 && radix == 4 && precision == SDSP_HIP_F32) ? PATH_FFT4096 : PATH_TILE;
+        if (n == 4096 && radix == 4 && precision == SDSP_HIP_F32)
+            p->path = PATH_FFT4096;
+        else if (precision == SDSP_HIP_F32 && fft_reg_supports(n, radix))
+            p->path = PATH_REG;
+        else
+            p->path = PATH_TILE;
         make_twiddles(n, direction, w);
         rc = upload_twiddles(w, precision, &p->tw);
         p->twiddle_bytes = (uint64_t)n * esize(precision);
@@ -486,6 +504,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = fft4096_kernel_name(p->variant);
     if (p->path == PATH_FFT1M && p->variant < 8)
         name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
+    if (p->path == PATH_REG && p->variant < 2)
+        name = "sdsp_fft_reg_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

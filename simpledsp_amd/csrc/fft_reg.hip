@@ -1,0 +1,334 @@
+// fft_reg.hip -- register-pass FFT family for gfx950: f32, N = 16 .. 4096, radix-2 stages
+// (sdsp::fft_radix2, fft.h:258-299) or radix-4 stages (sdsp::fft_radix4, fft.h:301-360), forward
+// or reverse.  Fast path for every batched size the tuned N=4096 radix-4 kernel does not cover.
+//
+// A 256-thread workgroup owns 4096 complex points = 4096/N consecutive transforms (32 KiB of the
+// batch, contiguous in HBM):
+//   1. the 32 KiB are copied HBM -> LDS with 16-byte lanes (fully coalesced, any N);
+//   2. ceil(log2 N / 4) passes: a thread pulls 16 points (stride N/16^(i+1)) of one transform from
+//      LDS into registers, runs four radix-2 DIF stages -- or two radix-4 DIF stages -- on them and
+//      puts them back in place; the last pass runs whatever stages remain (1..4);
+//   3. the result leaves LDS -> HBM coalesced again, the bit reversal (fft.h:269-273) or base-4 digit
+//      reversal (fft.h:351-355) being folded into the LDS read address of that copy.
+// Stage twiddles (fft.h:286 / :322-338) factor into a per-thread value read from the plan's
+// HBM-resident row W_N^j (L1/L2 resident: <= 32 KiB) and a compile-time W_16 constant.
+// LDS rows are padded by one slot per 16 so the strided pass accesses spread over the banks.
+// DIF ordering: natural input, reversed output, so no permutation pass is needed up front; results
+// agree with the reference to rounding (tests/test_gpu_fft.py, f32 tolerance 1e-6).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+constexpr float kC1 = 0.92387953251128673848f; // cos(pi/8)
+constexpr float kS1 = 0.38268343236508978178f; // sin(pi/8)
+constexpr float kH = 0.70710678118654752440f;  // sqrt(1/2)
+
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return float2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
+}
+template <bool REV> __device__ __forceinline__ float2 rot90(float2 a) // * -i (forward) / +i (reverse)
+{
+    return REV ? float2{ -a.y, a.x } : float2{ a.y, -a.x };
+}
+// a * W_16^E, E in [0, 16), compile-time
+template <bool REV, int E> __device__ __forceinline__ float2 mul_w16(float2 a)
+{
+    static_assert(E >= 0 && E < 16, "W_16 exponent");
+    if constexpr (E == 0) {
+        return a;
+    } else if constexpr (E == 4) {
+        return rot90<REV>(a);
+    } else if constexpr (E == 8) {
+        return float2{ -a.x, -a.y };
+    } else if constexpr (E == 12) {
+        return rot90<!REV>(a);
+    } else {
+        constexpr float c[16] = { 1.f, kC1, kH, kS1, 0.f, -kS1, -kH, -kC1, -1.f, -kC1, -kH, -kS1, 0.f, kS1, kH, kC1 };
+        constexpr float s[16] = { 0.f, kS1, kH, kC1, 1.f, kC1, kH, kS1, 0.f, -kS1, -kH, -kC1, -1.f, -kC1, -kH, -kS1 };
+        const float cr = c[E], ci = REV ? s[E] : -s[E]; // exp(-+ 2 pi i E / 16)
+        return float2{ a.x * cr - a.y * ci, a.x * ci + a.y * cr };
+    }
+}
+
+// ---- radix-2: stages J0..3 of the 4-stage DIF network on x[16]; stage j pairs (k, k + (8 >> j)).
+// w[j]: thread twiddle of stage j (ignored when !TW).
+template <bool REV, bool TW, int J0> struct r2_pass {
+    template <int J, int K> static __device__ __forceinline__ void bfly(float2 (&x)[16], const float2 (&w)[4])
+    {
+        constexpr int h = 8 >> J;
+        if constexpr ((K & h) == 0) {
+            const float2 a = x[K], b = x[K + h];
+            x[K] = a + b;
+            float2 d = mul_w16<REV, ((K & (h - 1)) << J) & 15>(a - b);
+            if constexpr (TW)
+                d = cmul(d, w[J]);
+            x[K + h] = d;
+        }
+    }
+    template <int J, int... Ks>
+    static __device__ __forceinline__ void stage(float2 (&x)[16], const float2 (&w)[4], std::integer_sequence<int, Ks...>)
+    {
+        (bfly<J, Ks>(x, w), ...);
+    }
+    static __device__ __forceinline__ void run(float2 (&x)[16], const float2 (&w)[4])
+    {
+        using seq = std::make_integer_sequence<int, 16>;
+        if constexpr (J0 <= 0)
+            stage<0>(x, w, seq{});
+        if constexpr (J0 <= 1)
+            stage<1>(x, w, seq{});
+        if constexpr (J0 <= 2)
+            stage<2>(x, w, seq{});
+        stage<3>(x, w, seq{});
+    }
+};
+
+// ---- radix-4: stage X pairs k = j + 4q over q (offset 4), stage Y pairs 4q + q' over q' (offset 1).
+// w1[q-1]: thread twiddle of stage X's output q; w2[q'-1]: of stage Y's output q'.  fft.h:342-345.
+template <bool REV> __device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = rot90<REV>(b - d);
+    a = t0 + t2;
+    b = t1 + t3;
+    c = t0 - t2;
+    d = t1 - t3;
+}
+template <bool REV, bool TW, bool BOTH>
+__device__ __forceinline__ void r4_pass(float2 (&x)[16], const float2 (&w1)[3], const float2 (&w2)[3])
+{
+    if constexpr (BOTH) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            bfly4<REV>(x[j], x[j + 4], x[j + 8], x[j + 12]);
+        x[5] = mul_w16<REV, 1>(x[5]);
+        x[6] = mul_w16<REV, 2>(x[6]);
+        x[7] = mul_w16<REV, 3>(x[7]);
+        x[9] = mul_w16<REV, 2>(x[9]);
+        x[10] = mul_w16<REV, 4>(x[10]);
+        x[11] = mul_w16<REV, 6>(x[11]);
+        x[13] = mul_w16<REV, 3>(x[13]);
+        x[14] = mul_w16<REV, 6>(x[14]);
+        x[15] = mul_w16<REV, 9>(x[15]);
+        if constexpr (TW) {
+#pragma unroll
+            for (int q = 1; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    x[j + 4 * q] = cmul(x[j + 4 * q], w1[q - 1]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        bfly4<REV>(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        if constexpr (TW) {
+            x[4 * q + 1] = cmul(x[4 * q + 1], w2[0]);
+            x[4 * q + 2] = cmul(x[4 * q + 2], w2[1]);
+            x[4 * q + 3] = cmul(x[4 * q + 3], w2[2]);
+        }
+    }
+}
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 gload16(const float4 *p)
+{
+    if constexpr (NT) {
+        const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+        return float4{ v.x, v.y, v.z, v.w };
+    } else {
+        return *p;
+    }
+}
+template <bool NT> __device__ __forceinline__ void gstore16(float4 *p, float4 a)
+{
+    if constexpr (NT) {
+        const v4f_t v = { a.x, a.y, a.z, a.w };
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(p));
+    } else {
+        *p = a;
+    }
+}
+
+constexpr int kPoints = 4096;                  // complex points per workgroup
+constexpr int kSlots = kPoints + kPoints / 16; // one padding slot per 16
+__device__ __forceinline__ uint32_t slot(uint32_t p) { return p + (p >> 4); }
+
+// reversed index of q within an N-point transform: bit reversal (radix 2) or base-4 digit reversal
+template <int RADIX, int LOG2N> __device__ __forceinline__ uint32_t reversed(uint32_t q)
+{
+    uint32_t r = __brev(q) >> (32 - LOG2N);
+    if constexpr (RADIX == 4)
+        r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
+    return r;
+}
+
+template <int RADIX, int LOG2N, bool REV, bool NT>
+__global__ __launch_bounds__(256) void sdsp_fft_reg_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                           uint64_t batch, float scale)
+{
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / 16;             // threads per transform
+    constexpr int G = kPoints / N;        // transforms per workgroup
+    constexpr int P = (LOG2N + 3) / 4;    // register passes
+    constexpr int LAST = LOG2N - 4 * (P - 1); // radix-2 stages left for the last pass (1..4)
+    static_assert(RADIX == 2 || (LOG2N % 2 == 0), "radix 4 needs a power of 4");
+    __shared__ __attribute__((aligned(16))) float2 lds[kSlots];
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t first = (uint64_t)blockIdx.x * G;             // first transform of this workgroup
+    const uint64_t have = batch - first < (uint64_t)G ? batch - first : (uint64_t)G;
+    const uint32_t live = (uint32_t)have * N;                    // valid points (ragged last workgroup)
+    float2 *base = data + first * N;
+
+    // 1. HBM -> LDS, 16 bytes per lane (two points), linear
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t e = 2 * (tid + 256 * k);
+        if (e < live) {
+            const float4 v = gload16<NT>(reinterpret_cast<const float4 *>(base + e));
+            lds[slot(e)] = float2{ v.x, v.y };
+            lds[slot(e + 1)] = float2{ v.z, v.w };
+        }
+    }
+    __syncthreads();
+
+    // 2. register passes, in place in LDS
+    const uint32_t g = tid / T, t = tid % T; // transform within the workgroup, thread within it
+    const uint32_t gbase = g * N;
+    float2 x[16];
+    auto run_pass = [&](auto pass_tag) {
+        constexpr int I = decltype(pass_tag)::value;
+        constexpr bool is_last = I == P - 1;
+        constexpr int S = is_last ? 1 : (N >> (4 * (I + 1))); // point stride of this pass
+        // thread (b, r): positions b*16*S + r + S*k
+        const uint32_t b = t / S, r = t % S;
+        const uint32_t p0 = gbase + b * 16 * S + r;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = lds[slot(p0 + S * k)];
+        constexpr bool TW = S > 1;          // r == 0 in the stride-1 pass: all thread twiddles are 1
+        const uint32_t unit = r << (4 * I); // r * 16^I: W_N^(unit * m) are this thread's twiddles
+        if constexpr (RADIX == 2) {
+            float2 w[4];
+            if constexpr (TW) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    w[j] = tw[unit << j];
+            }
+            r2_pass<REV, TW, is_last ? 4 - LAST : 0>::run(x, w);
+        } else {
+            float2 w1[3], w2[3];
+            if constexpr (TW) {
+#pragma unroll
+                for (int q = 1; q < 4; q++) {
+                    w1[q - 1] = tw[unit * q];
+                    w2[q - 1] = tw[unit * 4 * q];
+                }
+            }
+            r4_pass<REV, TW, !(is_last && LAST == 2)>(x, w1, w2);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            lds[slot(p0 + S * k)] = x[k];
+        __syncthreads();
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    if constexpr (P > 1)
+        run_pass(std::integral_constant<int, 1>{});
+    if constexpr (P > 2)
+        run_pass(std::integral_constant<int, 2>{});
+
+    // 3. LDS -> HBM: X[q] sits at position reversed(q) of its transform
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t e = 2 * (tid + 256 * k);
+        if (e < live) {
+            const uint32_t tb = e & ~(uint32_t)(N - 1), q = e & (N - 1);
+            float2 a = lds[slot(tb + reversed<RADIX, LOG2N>(q))];
+            float2 c = lds[slot(tb + reversed<RADIX, LOG2N>(q + 1))];
+            if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+                a.x *= scale;
+                a.y *= scale;
+                c.x *= scale;
+                c.y *= scale;
+            }
+            gstore16<NT>(reinterpret_cast<float4 *>(base + e), float4{ a.x, a.y, c.x, c.y });
+        }
+    }
+}
+
+template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr int G = kPoints >> LOG2N;
+    const uint64_t blocks = (a.batch + G - 1) / G;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    float2 *d = reinterpret_cast<float2 *>(a.data);
+    const float2 *w = reinterpret_cast<const float2 *>(a.tw);
+    const dim3 grid((uint32_t)blocks), block(256);
+    if (a.nontemporal) {
+        if (a.reverse)
+            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, true, true>), grid, block, 0, s, d, w, a.batch, a.scale);
+        else
+            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, false, true>), grid, block, 0, s, d, w, a.batch, a.scale);
+    } else {
+        if (a.reverse)
+            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, true, false>), grid, block, 0, s, d, w, a.batch, a.scale);
+        else
+            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, false, false>), grid, block, 0, s, d, w, a.batch, a.scale);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_reg launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+} // namespace
+
+bool fft_reg_supports(uint32_t n, int radix)
+{
+    if (n < 16 || n > 4096 || !sdsp_hip_is_power_of_2(n))
+        return false;
+    return radix == 2 || (radix == 4 && sdsp_hip_is_power_of_4(n));
+}
+
+int launch_fft_reg_f32(const fft_reg_args &a, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t l = sdsp_hip_log2(a.n);
+    if (a.radix == 2) {
+        switch (l) {
+        case 4: return launch_n<2, 4>(a, s);
+        case 5: return launch_n<2, 5>(a, s);
+        case 6: return launch_n<2, 6>(a, s);
+        case 7: return launch_n<2, 7>(a, s);
+        case 8: return launch_n<2, 8>(a, s);
+        case 9: return launch_n<2, 9>(a, s);
+        case 10: return launch_n<2, 10>(a, s);
+        case 11: return launch_n<2, 11>(a, s);
+        case 12: return launch_n<2, 12>(a, s);
+        default: break;
+        }
+    } else if (a.radix == 4) {
+        switch (l) {
+        case 4: return launch_n<4, 4>(a, s);
+        case 6: return launch_n<4, 6>(a, s);
+        case 8: return launch_n<4, 8>(a, s);
+        case 10: return launch_n<4, 10>(a, s);
+        case 12: return launch_n<4, 12>(a, s);
+        default: break;
+        }
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the register-pass kernels");
+}
+} // namespace sdsp_hip

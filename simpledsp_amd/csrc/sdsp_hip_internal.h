@@ -62,6 +62,20 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
 const char *fft4096_kernel_name(int variant);
 int fft4096_num_variants();
 
+// fast path for every other batched f32 size 16 .. 4096, radix 2 or 4 (register-pass family)
+struct fft_reg_args {
+    void *data;
+    const void *tw; // W_n^j
+    uint32_t n;
+    int radix;
+    uint64_t batch;
+    float scale;
+    int reverse;
+    int nontemporal;
+};
+bool fft_reg_supports(uint32_t n, int radix);
+int launch_fft_reg_f32(const fft_reg_args &a, void *stream);
+
 // fast path: batched n = 2^20, radix 2, f32 (BASELINE config 3), one chunk of transforms
 struct fft1m_args {
     void *data;          // count x 2^20 complex, in place

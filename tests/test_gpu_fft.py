@@ -117,6 +117,30 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
             assert err < (_tol64(n) if prec == sd.F64 else TOL32), (n, radix, rev, err)
 
 
+@pytest.mark.parametrize("n,radix,batch", [(16, 2, 1), (16, 4, 300), (32, 2, 129), (64, 4, 1000), (128, 2, 33), (256, 4, 17),
+                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (2048, 2, 3), (4096, 2, 5)])
+def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
+    # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
+    torch = torch_cuda
+    rng = np.random.default_rng(n * 7 + batch)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        want = oracle.fft(x.astype(np.complex128), radix, rev)
+        plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
+        assert plan.info.kernel.decode() == "sdsp_fft_reg_kernel"
+        outs = []
+        for variant in (0, 1, 99):  # streaming / default cache policy / coverage kernel
+            plan.set_variant(variant)
+            d = torch.from_numpy(x).cuda()
+            guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector
+            plan.exec(d)
+            torch.cuda.synchronize()
+            outs.append(d.cpu().numpy())
+            assert rel_max_err(outs[-1], want) < TOL32, (n, radix, rev, variant, rel_max_err(outs[-1], want))
+            assert bool((guard == 7.0 + 3.0j).all())
+        assert np.array_equal(outs[0], outs[1])
+
+
 def test_n1_is_identity(sd, torch_cuda):
     x = np.array([[1 + 2j], [3 - 1j]], np.complex64)
     assert np.array_equal(_run(sd, torch_cuda, x, 2, sd.forward_fft, sd.F32), x)
