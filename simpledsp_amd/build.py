@@ -22,16 +22,18 @@ OBJ_DIR = ROOT / "build" / "obj"
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{ROOT / 'include'}", f"-I{CSRC}",
           "-Wall", "-Wno-unused-function"]
-# per-source extra flags.  iir.hip keeps the reference's operation order (no FMA contraction) so
+# per-source extra flags.  -fno-slp-vectorize: packing scalar f32 math into v_pk_*_f32 buys nothing on
+# CDNA4's SIMD-32 and costs v_mov shuffles + register-pair constraints (measured: fft4096 +1.8 %,
+# fft_reg up to +7 %, fft1m +17 % and no scratch, iir -800 v_mov per kernel).  iir.hip keeps the reference's operation order (no FMA contraction) so
 # that the f64 kernel reproduces casc_2o_iir.h bit for bit.
 SOURCES = {
     "host_math.cpp": ["-x", "hip"],
     "capi.hip": [],
     "fft_tile.hip": [],
-    "fft4096.hip": [],
-    "fft1m.hip": [],
-    "fft_reg.hip": [],
-    "iir.hip": ["-ffp-contract=off"],
+    "fft4096.hip": ["-fno-slp-vectorize"],
+    "fft1m.hip": ["-fno-slp-vectorize"],  # SLP packing cost 44-76 B/lane of scratch here
+    "fft_reg.hip": ["-fno-slp-vectorize"],
+    "iir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
 }
 
 

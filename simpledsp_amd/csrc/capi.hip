@@ -158,7 +158,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (p->path == PATH_FFT1M && p->variant < 8) {
         // chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache
         // when pass 2 reads them (variant -> chunk size, for tuning)
-        static const uint64_t chunk_of[8] = { 16, 4, 8, 32, 2, 1, 12, 24 };
+        static const uint64_t chunk_of[8] = { 32, 4, 8, 16, 24, 1, 12, 2 }; // 48/64 overflow the 256 MiB cache: 20 % slower
         const uint64_t chunk = std::min<uint64_t>(chunk_of[p->variant], p->ws_batch);
         const uint64_t N = 1ull << 20;
         for (uint64_t done = 0; done < batch; done += chunk) {

@@ -3,9 +3,11 @@
 // Batched form of sdsp::casc_2o_iir<m_t>::process (casc_2o_iir.h:36-80) and of the
 // numerator-folded casc_2o_iir_{lp,hp,bp}::process_spec (:286-295, :344-353, :402-411): many
 // independent channels, shared coefficients, per-channel state.  One lane owns one channel and
-// runs the reference's Direct-Form-I recurrence with the reference's operation order (this file
-// is compiled with -ffp-contract=off, so the f64 kernel reproduces the reference's doubles
-// bit for bit and block-by-block streaming is bit-identical to one long call).
+// runs the reference's Direct-Form-I recurrence.  The f64 kernels keep the reference's exact
+// operation order (this file is compiled with -ffp-contract=off), so they reproduce the reference's
+// doubles bit for bit; the f32 kernels (parity by tolerance) fuse each multiply-subtract pair.  In
+// both, block-by-block streaming is bit-identical to one long call.  Built with -fno-slp-vectorize:
+// packing this scalar recurrence into v_pk_*_f32 cost ~1000 v_mov per kernel for no gain on SIMD-32.
 //
 // The path is HBM-bound (8 B per f32 sample, 33 flop): the work is in the data movement.  Each
 // channel's samples are contiguous in memory, so a lane reading "its" channel would touch one
@@ -83,7 +85,23 @@ __device__ __forceinline__ R cascade_step(R x, const iir_dev_args<R, M> &p, R (&
 #pragma unroll
     for (int j = 0; j < M; j++) {
         R acc = cur[j];
-        if constexpr (KIND == SDSP_HIP_IIR_GENERIC) { // :67-68
+        if constexpr (sizeof(R) == 4) {
+            // f32 (parity by tolerance, 1e-6): same terms, grouped as the reference groups them, but
+            // each "x*b - y*a" pair costs a multiply and an FMA instead of two multiplies and a subtract
+            if constexpr (KIND == SDSP_HIP_IIR_GENERIC) {
+                acc += __builtin_fmaf(y1[j], p.b1[j], -(y1[j + 1] * p.a1[j]));
+                acc += __builtin_fmaf(y2[j], p.b2[j], -(y2[j + 1] * p.a2[j]));
+            } else if constexpr (KIND == SDSP_HIP_IIR_LP) {
+                acc += __builtin_fmaf(-y1[j + 1], p.a1[j], y1[j] + y1[j]);
+                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], y2[j]);
+            } else if constexpr (KIND == SDSP_HIP_IIR_HP) {
+                acc += __builtin_fmaf(-y1[j + 1], p.a1[j], -y1[j] - y1[j]);
+                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], y2[j]);
+            } else {
+                acc += -y1[j + 1] * p.a1[j];
+                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], -y2[j]);
+            }
+        } else if constexpr (KIND == SDSP_HIP_IIR_GENERIC) { // :67-68
             acc += y1[j] * p.b1[j] - y1[j + 1] * p.a1[j];
             acc += y2[j] * p.b2[j] - y2[j + 1] * p.a2[j];
         } else if constexpr (KIND == SDSP_HIP_IIR_LP) { // :292-293
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
 // The super-tile stays in registers (128 VGPRs); its four 128-byte sub-tiles go through a padded
 // 9 KiB LDS transpose one after the other, and the filtered samples return to the same registers,
 // so the stores have the same burst shape as the loads.
-template <typename R, int KIND, int M, bool NT>
+template <typename R, int KIND, int M, bool NT, int SUBS>
 __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, M> p)
 {
     using V = typename vec16<R>::type;
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
     constexpr int T = ROWB / (int)sizeof(R);  // samples per sub-tile
     constexpr int NV = ROWB / 16;             // = 8 vectors per sub-row = lanes per row
     constexpr int RPI = 64 / NV;              // = 8 rows per wave-wide access
-    constexpr int SUBS = 4;                   // sub-tiles per super-tile (512 B per channel)
+    // SUBS = sub-tiles per super-tile: 4 -> 512 B per channel per burst, 128 data VGPRs
     constexpr int PITCH = ROWB + 16;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
@@ -373,21 +391,28 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
     // variants (identical arithmetic, bit-identical results):
     //   0 super-tile (default)                 1 super-tile, streaming (non-temporal) accesses
     //   2 tiled 128-byte rows, streaming       3 direct (any alignment)       4 tiled 256-byte rows
+    //   5 super-tile of 3 sub-tiles (384 B bursts, 3 waves/SIMD)   6 of 2 sub-tiles (256 B, 4 waves/SIMD)
     if (variant != 3 && !aligned)
         variant = 3; // shapes the vector kernels cannot address fall to the direct kernel
     if (variant == 3) {
         const uint64_t blocks = (a.channels + 255) / 256;
         hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
-    } else if (variant == 0 || variant == 1) {
+    } else if (variant == 0 || variant == 1 || variant == 5 || variant == 6) {
         const uint64_t blocks = (a.channels + 63) / 64;
         if (blocks > 0x7fffffffull)
             return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
         const size_t lds = 64 * (128 + 16);
         if (variant == 0) // measured: default policy 5.12 TB/s vs streaming 5.03 TB/s (f32, round 1)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+                               stream, p);
+        else if (variant == 1)
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+                               stream, p);
+        else if (variant == 5)
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 3>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 2>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
     } else {
         const uint64_t blocks = (a.channels + 255) / 256;

@@ -52,7 +52,7 @@ def test_octave_impulse_responses_f64(sd, torch_cuda, iir_golden, csv):
     x = np.zeros((3, want.size))
     x[:, 0] = 1.0
     for kind, key in ((sd.IIR_GENERIC, "generic"), (ftype, "spec")):
-        for variant in (0, 1, 2, 3, 4):
+        for variant in (0, 1, 2, 3, 4, 5, 6):
             bank = _bank(sd, 4, 3, sd.F64, kind, ftype, f0, fs, q, variant=variant)
             out = _process(torch_cuda, bank, x)
             assert np.abs(out - want).max() < 1e-12
@@ -125,7 +125,7 @@ def test_f32_bank_against_oracle(sd, torch_cuda, oracle, channels, samples):
     x = rng.standard_normal((channels, samples)).astype(np.float32)
     pick = sorted(set([0, channels - 1] + list(rng.choice(channels, min(channels, 8)))))
     results = {}
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         bank = _bank(sd, 4, channels, sd.F32, sd.IIR_GENERIC, 1, 10e3, 100e3, 0.0, variant=variant)
         results[variant] = _process(torch_cuda, bank, x)
     for c in pick:
@@ -134,7 +134,7 @@ def test_f32_bank_against_oracle(sd, torch_cuda, oracle, channels, samples):
         want = fo.process(x[c].astype(np.float64))
         assert rel_max_err(results[0][c], want) < 1e-6, (c, rel_max_err(results[0][c], want))
     # all kernel variants run the same arithmetic in the same order
-    assert all(np.array_equal(results[0], results[v]) for v in (1, 2, 3, 4))
+    assert all(np.array_equal(results[0], results[v]) for v in (1, 2, 3, 4, 5, 6))
 
 
 def test_f32_specialised_kinds_and_streaming(sd, torch_cuda, oracle):
