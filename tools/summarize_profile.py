@@ -82,8 +82,8 @@ for k, c in pm.items():
     traffic[k] = {"hbm_bytes_per_launch": b, "fetch_size_kib_raw": f, "write_size_kib": wv, "profile": tag}
     lines.append(f"| `{k}` | {f:.1f} | {wv:.1f} | {b:.4g} |")
 # launches of each kernel per bench step: 1, except the chunked N=2^20 path (256 transforms per step
-# in chunks of 16 -> 16 launches of each pass, csrc/capi.hip)
-LAUNCHES_PER_STEP = {"sdsp_fft1m_cols": 16, "sdsp_fft1m_rows": 16}
+# in chunks of 32 -> 8 launches of each pass, csrc/capi.hip)
+LAUNCHES_PER_STEP = {"sdsp_fft1m_cols": 8, "sdsp_fft1m_rows": 8}
 for k in traffic:
     traffic[k]["launches_per_step"] = LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
 alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
