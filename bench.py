@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_il"])
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the per-GPU unit count")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,12 +97,12 @@ def make_fft1m(sd, torch, dev, args):
     return step, batch, int(info.algorithmic_bytes), desc, "batched complex FFTs/sec (N=2^20, radix-2, fp32)", "FFT/s", "f32", (fwd, rev, x)
 
 
-def make_iir(sd, torch, dev, args, f64=False):
+def make_iir(sd, torch, dev, args, f64=False, interleaved=False):
     channels = args.batch_per_gpu or (1 << 20)
     samples = 4096
     dt = torch.float64 if f64 else torch.float32
     g = torch.Generator(device=dev).manual_seed(0x5D5B + 2 + dev.index)
-    x = torch.randn((channels, samples), generator=g, device=dev, dtype=dt)
+    x = torch.randn((samples, channels) if interleaved else (channels, samples), generator=g, device=dev, dtype=dt)
     bank = sd.casc_2o_iir(4, channels, sd.F64 if f64 else sd.F32, sd.IIR_GENERIC, device=dev.index)
     bank.set_lp_coeff(10e3, 100e3)  # testIIR.cpp:469-474
     if args.variant >= 0:
@@ -110,13 +110,17 @@ def make_iir(sd, torch, dev, args, f64=False):
 
     def step():
         bank.reset()
-        bank.process(x)  # unity-DC-gain low-pass: repeated filtering stays bounded
+        if interleaved:
+            bank.process_interleaved(x)
+        else:
+            bank.process(x)  # unity-DC-gain low-pass: repeated filtering stays bounded
 
     bank.reset()
     desc = {
         "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place",
         "sections": 4, "channels_per_gpu": channels, "samples": samples,
-        "kernel": "sdsp_iir_supertile_kernel",
+        "kernel": "sdsp_iir_interleaved_kernel" if interleaved else "sdsp_iir_supertile_kernel",
+        "layout": "sample-major [sample][channel] (SURVEY 8f-2)" if interleaved else "channel-major (BASELINE)",
     }
     unit_bytes = 16 if f64 else 8
     return step, channels * samples, unit_bytes, desc, "IIR samples/sec (4 cascaded biquads, LP)", "samples/s", "f64" if f64 else "f32", (bank, x)
@@ -222,7 +226,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     mk = {"fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
-          "iir64": lambda *a: make_iir(*a, f64=True)}[args.workload]
+          "iir64": lambda *a: make_iir(*a, f64=True),
+          "iir_il": lambda *a: make_iir(*a, interleaved=True)}[args.workload]
     step, units, unit_bytes, desc, metric, unit, dtype, keep = mk(sd, torch, dev, args)
 
     # Setup, not measurement: wake the device up.  The first ~20 back-to-back launches after idle run

@@ -171,6 +171,15 @@ int sdsp_hip_iir_plan_destroy(sdsp_hip_iir_plan *plan);
  */
 int sdsp_hip_iir_process(sdsp_hip_iir_plan *plan, void *data, uint64_t channels,
                          uint64_t samples, uint64_t stride, void *state, void *stream);
+/*
+ * The same filter bank on the interleaved ("wire") layout: sample s of channel c is
+ * data[s*stride + c] (stride >= channels elements between consecutive sample rows), i.e. what an
+ * ADC / network frame delivers.  No transpose is needed, so this is the fastest entry; results are
+ * bit-identical to sdsp_hip_iir_process on the transposed data.  Fast path: rows 8-byte aligned and
+ * an even channel count for f32 (any 4-byte aligned f32 shape still works).  SURVEY 8(f)-2.
+ */
+int sdsp_hip_iir_process_interleaved(sdsp_hip_iir_plan *plan, void *data, uint64_t channels,
+                                     uint64_t samples, uint64_t stride, void *state, void *stream);
 /* same with HOST pointers (synchronous) */
 int sdsp_hip_iir_process_host(sdsp_hip_iir_plan *plan, void *host_data, uint64_t channels,
                               uint64_t samples, uint64_t stride, void *host_state);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sdsp_hip_iir_plan_create": (_i, [_pp, _u32, _i, _vp, _vp, _d, _i, _i]),
     "sdsp_hip_iir_plan_destroy": (_i, [_vp]),
     "sdsp_hip_iir_process": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "sdsp_hip_iir_process_interleaved": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "sdsp_hip_iir_process_host": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "sdsp_hip_iir_process_sharded": (_i, [_pp, _i, _vp, _u64, _u64]),
     "sdsp_hip_iir_state_bytes": (_i, [_vp, _u64, C.POINTER(_u64)]),

@@ -9,6 +9,12 @@
 
 #include "sdsp_hip_internal.h"
 
+// one pass of the tuned 2^20 path (defined in fft1m.hip): which = 1 columns pass, 2 rows pass
+namespace sdsp_hip
+{
+int launch_fft1m_pass(const fft1m_args &a, int which, void *stream);
+}
+
 using namespace sdsp_hip;
 
 namespace
@@ -79,6 +85,9 @@ struct sdsp_hip_fft_plan {
     uint64_t twiddle_bytes = 0;
     void *host_stage = nullptr;    // device staging buffer of the *_host path
     uint64_t host_stage_bytes = 0;
+    // two-stream pipelining of the N=2^20 passes (created on first use)
+    hipStream_t aux_stream = nullptr;
+    std::vector<hipEvent_t> events;
 };
 
 struct sdsp_hip_iir_plan {
@@ -156,23 +165,61 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     }
 
     if (p->path == PATH_FFT1M && p->variant < 8) {
-        // chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache
-        // when pass 2 reads them (variant -> chunk size, for tuning)
-        static const uint64_t chunk_of[8] = { 32, 4, 8, 16, 24, 1, 12, 2 }; // 48/64 overflow the 256 MiB cache: 20 % slower
-        const uint64_t chunk = std::min<uint64_t>(chunk_of[p->variant], p->ws_batch);
+        // Chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache when
+        // pass 2 reads them.  variant -> (chunk, overlap).  With overlap the workspace is used as two
+        // halves and pass 1 of chunk i+1 (HBM reads) runs on the caller's stream while pass 2 of
+        // chunk i (HBM writes) runs on an internal stream; events order the hand-offs.
+        static const uint64_t chunk_of[8] = { 32, 16, 16, 8, 24, 12, 8, 4 };
+        static const bool overlap_of[8] = { false, true, false, true, false, true, false, true };
+        const bool overlap = overlap_of[p->variant];
+        const uint64_t cap = overlap ? p->ws_batch / 2 : p->ws_batch;
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk_of[p->variant], cap));
         const uint64_t N = 1ull << 20;
-        for (uint64_t done = 0; done < batch; done += chunk) {
+        auto args_for = [&](uint64_t done, int half) {
             fft1m_args a;
             a.data = reinterpret_cast<char *>(data) + done * N * 8;
-            a.workspace = p->workspace;
+            a.workspace = reinterpret_cast<char *>(p->workspace) + (half ? chunk * N * 8 : 0);
             a.tw_n = p->tw;
             a.tw_1024 = p->tw1;
             a.count = std::min<uint64_t>(chunk, batch - done);
             a.scale = (float)(1.0 / (double)N);
             a.reverse = rev;
-            if (int rc = launch_fft1m_r2_f32(a, stream))
-                return rc;
+            return a;
+        };
+        if (!overlap) {
+            for (uint64_t done = 0; done < batch; done += chunk) {
+                const fft1m_args a = args_for(done, 0);
+                if (int rc = launch_fft1m_pass(a, 1, stream))
+                    return rc;
+                if (int rc = launch_fft1m_pass(a, 2, stream))
+                    return rc;
+            }
+            return SDSP_HIP_OK;
         }
+        if (!p->aux_stream)
+            HIP_TRY(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+        const uint64_t n_chunks = (batch + chunk - 1) / chunk;
+        while (p->events.size() < 2 * n_chunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            p->events.push_back(e);
+        }
+        for (uint64_t i = 0; i < n_chunks; i++) {
+            const fft1m_args a = args_for(i * chunk, (int)(i & 1));
+            hipEvent_t cols_done = p->events[2 * i], rows_done = p->events[2 * i + 1];
+            if (i >= 2) // this workspace half was last read by pass 2 of chunk i-2
+                HIP_TRY(hipStreamWaitEvent(stream, p->events[2 * (i - 2) + 1], 0));
+            if (int rc = launch_fft1m_pass(a, 1, stream))
+                return rc;
+            HIP_TRY(hipEventRecord(cols_done, stream));
+            HIP_TRY(hipStreamWaitEvent(p->aux_stream, cols_done, 0));
+            if (int rc = launch_fft1m_pass(a, 2, p->aux_stream))
+                return rc;
+            HIP_TRY(hipEventRecord(rows_done, p->aux_stream));
+        }
+        // the caller's stream is complete only when every pass 2 is
+        for (uint64_t i = (n_chunks >= 2 ? n_chunks - 2 : 0); i < n_chunks; i++)
+            HIP_TRY(hipStreamWaitEvent(stream, p->events[2 * i + 1], 0));
         return SDSP_HIP_OK;
     }
 
@@ -402,6 +449,10 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->tw2);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
+        for (hipEvent_t e : p->events)
+            (void)hipEventDestroy(e);
+        if (p->aux_stream)
+            (void)hipStreamDestroy(p->aux_stream);
     }
     delete p;
     return SDSP_HIP_OK;
@@ -614,6 +665,37 @@ int sdsp_hip_iir_process(sdsp_hip_iir_plan *p, void *data, uint64_t channels, ui
         a.b2[j] = p->b[3 * j + 2];
     }
     return launch_iir(p->precision, a, p->variant, stream);
+}
+
+int sdsp_hip_iir_process_interleaved(sdsp_hip_iir_plan *p, void *data, uint64_t channels, uint64_t samples,
+                                     uint64_t stride, void *state, void *stream)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (stride < channels && samples > 1)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "stride must be >= channels");
+    if (int rc = use_device(p->device))
+        return rc;
+    iir_args a{};
+    a.data = data;
+    a.state = state;
+    a.channels = channels;
+    a.samples = samples;
+    a.stride = stride;
+    a.sections = p->sections;
+    a.kind = p->kind;
+    a.gain = p->gain;
+    for (uint32_t j = 0; j < p->sections; j++) {
+        a.a1[j] = p->a[3 * j + 1];
+        a.a2[j] = p->a[3 * j + 2];
+        a.b1[j] = p->b[3 * j + 1];
+        a.b2[j] = p->b[3 * j + 2];
+    }
+    return launch_iir_interleaved(p->precision, a, p->variant, stream);
 }
 
 int sdsp_hip_iir_process_host(sdsp_hip_iir_plan *p, void *host_data, uint64_t channels, uint64_t samples,

@@ -298,8 +298,9 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
 }
 } // namespace
 
-// One chunk: `count` transforms, data -> workspace -> data.  The workspace holds `count` matrices.
-int launch_fft1m_r2_f32(const fft1m_args &a, void *stream)
+// One pass over one chunk of `count` transforms: which = 1 columns (data -> workspace),
+// which = 2 rows (workspace -> data).  The workspace holds `count` matrices.
+int launch_fft1m_pass(const fft1m_args &a, int which, void *stream)
 {
     if (a.count == 0)
         return SDSP_HIP_OK;
@@ -322,18 +323,28 @@ int launch_fft1m_r2_f32(const fft1m_args &a, void *stream)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds);
         attr_set = true;
     }
-    if (a.reverse) {
-        hipLaunchKernelGGL(sdsp_fft1m_cols<true>, dim3((uint32_t)blocks), dim3(kThreads), kColsLds, s, in, ws, twn, tw1k, tiles);
-        hipLaunchKernelGGL(sdsp_fft1m_rows<true>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, ws, out, tw1k, tiles,
-                           a.scale);
+    const dim3 grid((uint32_t)blocks), block(kThreads);
+    if (which == 1) {
+        if (a.reverse)
+            hipLaunchKernelGGL(sdsp_fft1m_cols<true>, grid, block, kColsLds, s, in, ws, twn, tw1k, tiles);
+        else
+            hipLaunchKernelGGL(sdsp_fft1m_cols<false>, grid, block, kColsLds, s, in, ws, twn, tw1k, tiles);
     } else {
-        hipLaunchKernelGGL(sdsp_fft1m_cols<false>, dim3((uint32_t)blocks), dim3(kThreads), kColsLds, s, in, ws, twn, tw1k, tiles);
-        hipLaunchKernelGGL(sdsp_fft1m_rows<false>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, ws, out, tw1k, tiles,
-                           a.scale);
+        if (a.reverse)
+            hipLaunchKernelGGL(sdsp_fft1m_rows<true>, grid, block, 0, s, ws, out, tw1k, tiles, a.scale);
+        else
+            hipLaunchKernelGGL(sdsp_fft1m_rows<false>, grid, block, 0, s, ws, out, tw1k, tiles, a.scale);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft1m launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
+}
+
+int launch_fft1m_r2_f32(const fft1m_args &a, void *stream)
+{
+    if (int rc = launch_fft1m_pass(a, 1, stream))
+        return rc;
+    return launch_fft1m_pass(a, 2, stream);
 }
 } // namespace sdsp_hip

@@ -365,6 +365,89 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
         store_state<R, M>(p, my_ch, y1, y2, y3);
 }
 
+// ---- interleaved ("wire") layout, SURVEY 8(f)-2: data[s * stride + c], channels contiguous.  No
+// transpose at all: a lane owns VEC ADJACENT channels and runs their recurrences side by side
+// (independent dependency chains), a wave moves 64*VEC*sizeof(R) contiguous bytes of one sample row
+// per instruction, and U rows are fetched ahead of the U rows being filtered.
+template <typename R, int VEC> struct alignas(sizeof(R) * VEC) chan_vec {
+    R v[VEC];
+};
+template <typename R, int VEC, bool NT> __device__ __forceinline__ chan_vec<R, VEC> gload_cv(const R *p)
+{
+    using N = R __attribute__((ext_vector_type(VEC)));
+    chan_vec<R, VEC> out;
+    if constexpr (VEC == 1) {
+        out.v[0] = NT ? __builtin_nontemporal_load(p) : *p;
+    } else if constexpr (NT) {
+        const N v = __builtin_nontemporal_load(reinterpret_cast<const N *>(p));
+        __builtin_memcpy(&out, &v, sizeof(out));
+    } else {
+        out = *reinterpret_cast<const chan_vec<R, VEC> *>(p);
+    }
+    return out;
+}
+template <typename R, int VEC, bool NT> __device__ __forceinline__ void gstore_cv(R *p, const chan_vec<R, VEC> &a)
+{
+    using N = R __attribute__((ext_vector_type(VEC)));
+    if constexpr (VEC == 1) {
+        if constexpr (NT)
+            __builtin_nontemporal_store(a.v[0], p);
+        else
+            *p = a.v[0];
+    } else if constexpr (NT) {
+        N v;
+        __builtin_memcpy(&v, &a, sizeof(a));
+        __builtin_nontemporal_store(v, reinterpret_cast<N *>(p));
+    } else {
+        *reinterpret_cast<chan_vec<R, VEC> *>(p) = a;
+    }
+}
+
+template <typename R, int KIND, int M, bool NT, int VEC, int U>
+__global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R, M> p)
+{
+    using V = chan_vec<R, VEC>;
+    const uint64_t c0 = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * VEC;
+    if (c0 >= p.channels)
+        return; // channels is a multiple of VEC (checked by the host)
+
+    R y1[VEC][M + 1], y2[VEC][M + 1], y3[VEC][M + 1];
+#pragma unroll
+    for (int e = 0; e < VEC; e++)
+        load_state<R, M>(p, c0 + e, y1[e], y2[e], y3[e]);
+
+    R *col = p.data + c0;
+    V cur[U], nxt[U];
+    auto fetch = [&](V (&dst)[U], uint64_t s0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dst[u] = V{};
+            if (s0 + u < p.samples)
+                dst[u] = gload_cv<R, VEC, NT>(col + (s0 + u) * p.stride);
+        }
+    };
+    fetch(cur, 0);
+    for (uint64_t s0 = 0; s0 < p.samples; s0 += U) {
+        if (s0 + U < p.samples)
+            fetch(nxt, s0 + U);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (s0 + u < p.samples) {
+#pragma unroll
+                for (int e = 0; e < VEC; e++)
+                    cur[u].v[e] = cascade_step<R, KIND, M>(cur[u].v[e], p, y1[e], y2[e], y3[e]);
+                gstore_cv<R, VEC, NT>(col + (s0 + u) * p.stride, cur[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++)
+        store_state<R, M>(p, c0 + e, y1[e], y2[e], y3[e]);
+}
+
 template <typename R, int M> iir_dev_args<R, M> make_args(const iir_args &a)
 {
     iir_dev_args<R, M> p;
@@ -460,6 +543,75 @@ template <typename R> int launch_r(const iir_args &a, int variant, hipStream_t s
     }
 }
 } // namespace
+
+namespace
+{
+template <typename R, int KIND, int M, int VEC, int U>
+int launch_il_v(const iir_args &a, bool nt, hipStream_t stream)
+{
+    if (((uintptr_t)a.data % (sizeof(R) * VEC)) || ((a.stride * sizeof(R)) % (sizeof(R) * VEC)) || (a.channels % VEC))
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "interleaved layout: data/stride/channels must be multiples of the lane width");
+    const auto p = make_args<R, M>(a);
+    const uint64_t blocks = (a.channels / VEC + 63) / 64;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    if (nt)
+        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<R, KIND, M, true, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
+    else
+        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<R, KIND, M, false, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("iir interleaved launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+// variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming
+// (measured 63.9 % of HBM peak, round 1); 1 = 8-byte lanes, streaming (58 %); 2 = 8-byte lanes,
+// default cache policy (57 %); 3 = 4-byte lanes, f32 only (58 %).  Narrower shapes fall through.
+template <typename R, int KIND, int M> int launch_il_km(const iir_args &a, int variant, hipStream_t stream)
+{
+    constexpr int V8 = 8 / (int)sizeof(R), V16 = 16 / (int)sizeof(R);
+    const bool a16 = !((uintptr_t)a.data % 16) && !((a.stride * sizeof(R)) % 16) && !(a.channels % V16);
+    const bool a8 = !((uintptr_t)a.data % 8) && !((a.stride * sizeof(R)) % 8) && !(a.channels % V8);
+    if (variant == 0 && a16)
+        return launch_il_v<R, KIND, M, V16, 4>(a, true, stream);
+    if constexpr (sizeof(R) == 4) {
+        if (variant == 3 || !a8)
+            return launch_il_v<R, KIND, M, 1, 8>(a, true, stream);
+    }
+    if (a8)
+        return launch_il_v<R, KIND, M, V8, 8>(a, variant != 2, stream);
+    return fail(SDSP_HIP_ERR_INVALID_ARG, "interleaved layout needs 8-byte aligned rows");
+}
+template <typename R, int KIND> int launch_il_k(const iir_args &a, int variant, hipStream_t stream)
+{
+    switch (a.sections) {
+    case 2: return launch_il_km<R, KIND, 2>(a, variant, stream);
+    case 4: return launch_il_km<R, KIND, 4>(a, variant, stream);
+    case 6: return launch_il_km<R, KIND, 6>(a, variant, stream);
+    case 8: return launch_il_km<R, KIND, 8>(a, variant, stream);
+    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be 2, 4, 6 or 8");
+    }
+}
+template <typename R> int launch_il_r(const iir_args &a, int variant, hipStream_t stream)
+{
+    switch (a.kind) {
+    case SDSP_HIP_IIR_GENERIC: return launch_il_k<R, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
+    case SDSP_HIP_IIR_LP: return launch_il_k<R, SDSP_HIP_IIR_LP>(a, variant, stream);
+    case SDSP_HIP_IIR_HP: return launch_il_k<R, SDSP_HIP_IIR_HP>(a, variant, stream);
+    case SDSP_HIP_IIR_BP: return launch_il_k<R, SDSP_HIP_IIR_BP>(a, variant, stream);
+    default: return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
+    }
+}
+} // namespace
+
+// data[s * stride + c]: sample-major ("interleaved") layout
+int launch_iir_interleaved(int precision, const iir_args &a, int variant, void *stream)
+{
+    if (a.channels == 0 || a.samples == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return precision == SDSP_HIP_F64 ? launch_il_r<double>(a, variant, s) : launch_il_r<float>(a, variant, s);
+}
 
 int launch_iir(int precision, const iir_args &a, int variant, void *stream)
 {

@@ -102,4 +102,5 @@ struct iir_args {
     double b1[SDSP_HIP_MAX_SECTIONS], b2[SDSP_HIP_MAX_SECTIONS];
 };
 int launch_iir(int precision, const iir_args &a, int variant, void *stream);
+int launch_iir_interleaved(int precision, const iir_args &a, int variant, void *stream);
 } // namespace sdsp_hip

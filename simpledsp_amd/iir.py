@@ -123,6 +123,28 @@ class casc_2o_iir:
                                                self.channels, samples, stride, self._state.data_ptr(), stream))
         return data
 
+    def process_interleaved(self, data, samples: int | None = None, offset: int = 0):
+        """data: contiguous device tensor (samples, channels) -- the sample-major "wire" layout
+        (SURVEY 8f-2).  Filters rows offset..offset+samples in place, continuing from the bank's
+        state; bit-identical to process() on the transposed data, without any transpose."""
+        import torch
+        dt = torch.float64 if self.precision == L.F64 else torch.float32
+        if data.dtype != dt or not data.is_cuda or not data.is_contiguous() or data.dim() != 2:
+            raise ValueError("process_interleaved needs a contiguous (samples, channels) device tensor")
+        if data.shape[1] != self.channels:
+            raise ValueError("channel count differs from the bank's")
+        samples = data.shape[0] - offset if samples is None else samples
+        if offset + samples > data.shape[0]:
+            raise ValueError("block exceeds the buffer")
+        self._ensure_plan()
+        if self._state is None:
+            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=data.device)
+        stream = torch.cuda.current_stream(data.device).cuda_stream
+        L.check(self._lib.sdsp_hip_iir_process_interleaved(
+            self._plan, data.data_ptr() + offset * self.channels * data.element_size(), self.channels, samples,
+            self.channels, self._state.data_ptr(), stream))
+        return data
+
     def __del__(self):
         try:
             self._drop_plan()

@@ -195,6 +195,29 @@ def test_four_step_large_transforms(sd, torch_cuda, oracle, n, radix, batch):
         assert rel_max_err(got64, want) < _tol64(n)
 
 
+def test_fft1m_chunking_and_two_stream_variants_agree(sd, torch_cuda, oracle):
+    # N = 2^20 radix-2: serial chunks, two-stream overlapped chunks (double-buffered workspace) and the
+    # coverage kernel compute the same transform; batch 37 is ragged against every chunk size
+    torch = torch_cuda
+    n, batch = 1 << 20, 37
+    g = torch.Generator(device="cuda").manual_seed(20)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device="cuda"))
+    want = oracle.fft(x[[0, 17, 36]].cpu().numpy().astype(np.complex128), 2)
+    plan = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch)
+    first = None
+    for variant in (0, 1, 3, 5, 7, 6):
+        plan.set_variant(variant)
+        y = x.clone()
+        plan.exec(y)
+        plan.exec(y.clone())  # a second call right behind it must not disturb the first one's result
+        torch.cuda.synchronize()
+        assert rel_max_err(y[[0, 17, 36]].cpu().numpy(), want) < TOL32, variant
+        if first is None:
+            first = y
+        else:
+            assert torch.equal(first, y), variant
+
+
 def test_plan_twiddles_are_the_rounded_reference_row(sd, torch_cuda, fft_golden):
     # a4: the HBM-resident table equals the reference's last table row rounded once to fp32
     plan = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32)

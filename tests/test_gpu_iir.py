@@ -157,6 +157,37 @@ def test_f32_specialised_kinds_and_streaming(sd, torch_cuda, oracle):
             assert np.array_equal(d.cpu().numpy(), whole), (nm, blk)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_interleaved_layout_is_bit_identical_to_channel_major(sd, torch_cuda, precision):
+    # the sample-major "wire" layout -- same arithmetic, no transpose
+    torch = torch_cuda
+    prec = sd.F32 if precision == "f32" else sd.F64
+    dt = torch.float32 if prec == sd.F32 else torch.float64
+    rng = np.random.default_rng(3)
+    for channels, samples in ((4, 50), (260, 333), (1024, 1000), (7, 40)):
+        x = torch.from_numpy(rng.standard_normal((channels, samples))).to(dt).cuda()
+        for nm, ftype in KINDS.items():
+            for kind in (sd.IIR_GENERIC, ftype):
+                ref = _bank(sd, 4, channels, prec, kind, ftype, 10e3, 100e3, 1.1)
+                want = x.clone()
+                ref.process(want)
+                if channels % 2 and prec == sd.F64:
+                    continue  # f64 rows must be 8-byte... every f64 shape is; odd counts are an f32 case
+                for variant in (0, 1, 2, 3):
+                    bank = _bank(sd, 4, channels, prec, kind, ftype, 10e3, 100e3, 1.1, variant=variant)
+                    y = x.t().contiguous()  # (samples, channels)
+                    # stream it in ragged row blocks: state must carry across calls bit-exactly
+                    off = 0
+                    for blk in (7, 64, samples):
+                        n = min(blk, samples - off)
+                        if n > 0:
+                            bank.process_interleaved(y, samples=n, offset=off)
+                            off += n
+                    torch.cuda.synchronize()
+                    assert torch.equal(y.t(), want), (channels, samples, nm, kind, variant)
+                    assert torch.equal(bank.state, ref.state)
+
+
 def test_host_pointer_entry_point(sd, torch_cuda, iir_golden):
     import ctypes as C
     from simpledsp_amd import _lib as L

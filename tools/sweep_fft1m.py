@@ -12,8 +12,8 @@ dev = torch.device("cuda:0")
 x = torch.view_as_complex(torch.randn((batch, n, 2), device=dev))
 fwd = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch)
 rev = sd.FftPlan(n, 2, sd.reverse_fft, sd.F32, max_batch=batch)
-chunk_of = {0: 32, 1: 4, 2: 8, 3: 16, 4: 24, 5: 1, 6: 12, 7: 2, 99: "generic"}
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 3, 4]
+chunk_of = {0: "32", 1: "16 overlap", 2: "16", 3: "8 overlap", 4: "24", 5: "12 overlap", 6: "8", 7: "4 overlap", 99: "generic"}
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 3, 5, 7, 2]
 for v in variants:
     fwd.set_variant(v); rev.set_variant(v)
     for _ in range(2):
