@@ -58,6 +58,7 @@ SIGNATURES = {
     "sdsp_hip_fft_exec": (_i, [_vp, _vp, _u64, _vp]),
     "sdsp_hip_fft_exec_host": (_i, [_vp, _vp, _u64]),
     "sdsp_hip_fft_exec_sharded": (_i, [_pp, _i, _vp, _u64]),
+    "sdsp_hip_fft_convolve": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "sdsp_hip_fft_plan_get_info": (_i, [_vp, C.POINTER(PlanInfo)]),
     "sdsp_hip_fft_plan_get_twiddles": (_i, [_vp, _vp]),
     "sdsp_hip_fft_plan_set_variant": (_i, [_vp, _i]),

@@ -88,6 +88,7 @@ struct sdsp_hip_fft_plan {
     // two-stream pipelining of the N=2^20 passes (created on first use)
     hipStream_t aux_stream = nullptr;
     std::vector<hipEvent_t> events;
+    sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
 };
 
 struct sdsp_hip_iir_plan {
@@ -449,6 +450,10 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->tw2);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
+        if (p->partner)
+            sdsp_hip_fft_plan_destroy(p->partner);
+        p->partner = nullptr;
+        (void)hipSetDevice(p->device);
         for (hipEvent_t e : p->events)
             (void)hipEventDestroy(e);
         if (p->aux_stream)
@@ -534,6 +539,37 @@ int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void
         if (rcs[g])
             return fail(rcs[g], errs[g]);
     return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint64_t batch, void *stream)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (p->direction != SDSP_HIP_FORWARD)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "convolve needs a forward plan");
+    if (batch == 0)
+        return SDSP_HIP_OK;
+    if (!data || !h)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null pointer");
+    if (int rc = use_device(p->device))
+        return rc;
+    if (p->path == PATH_FFT4096 && p->variant == 0)
+        return launch_fft4096_conv_f32(data, p->tw, h, batch, stream);
+    if (!p->partner) {
+        if (int rc = sdsp_hip_fft_plan_create(&p->partner, p->n, p->radix, SDSP_HIP_REVERSE, p->precision,
+                                              p->max_batch, p->device))
+            return rc;
+    }
+    const int keep = p->variant;
+    if (p->path == PATH_FFT4096) // variant != 0 selects the three-launch path for cross-checking
+        p->variant = 0;
+    int rc = fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream));
+    p->variant = keep;
+    if (!rc)
+        rc = launch_pointwise_mul(p->precision, data, h, p->n, batch, stream);
+    if (!rc)
+        rc = fft_exec_device(p->partner, data, batch, reinterpret_cast<hipStream_t>(stream));
+    return rc;
 }
 
 int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_info *info)

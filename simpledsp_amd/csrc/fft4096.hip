@@ -274,6 +274,121 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused fast convolution: y = IFFT( FFT(x) .* H ) per transform in ONE kernel.
+// The forward transform above leaves thread t holding X[t + 256 j], j < 16 -- which is exactly the
+// layout its own first pass consumes -- so after the per-bin multiply the reverse transform (fft.h
+// reverse_fft policy: conjugate twiddles, +i rotations, 1/N scale) runs on the same registers and the
+// same LDS tile.  HBM sees one read and one write per element instead of three of each.
+
+struct lds_map {
+    float2 *b_even, *b_odd; // pass B bases (see sdsp_fft4096_r4_f32)
+    uint32_t c_base, c_x, t;
+};
+
+// all six stages on one transform held as x[k] = element t + 256 k; returns with
+// x[k] = result[t + 256 * (4 (k & 3) + (k >> 2))].  w*: FORWARD twiddles (conjugated here when REV).
+template <bool REV>
+__device__ __forceinline__ void fft4096_in_regs(float2 (&x)[16], float2 *lds, const lds_map &mp,
+                                                const float2 (&wA1)[3], const float2 (&wA2)[3],
+                                                const float2 (&wB1)[3], const float2 (&wB2)[3])
+{
+    float2 a1[3], a2[3], b1[3], b2[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        a1[r] = float2{ wA1[r].x, REV ? -wA1[r].y : wA1[r].y };
+        a2[r] = float2{ wA2[r].x, REV ? -wA2[r].y : wA2[r].y };
+        b1[r] = float2{ wB1[r].x, REV ? -wB1[r].y : wB1[r].y };
+        b2[r] = float2{ wB2[r].x, REV ? -wB2[r].y : wB2[r].y };
+    }
+    two_stages<REV, true, true>(x, a1, a2);
+    {
+        uint32_t ta = mp.t;
+        asm volatile("" : "+v"(ta));
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            lds[256 * k + (ta ^ ((__brev((uint32_t)k) >> 28) << 1))] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        x[k] = (k & 1) ? mp.b_odd[16 * k] : mp.b_even[16 * k];
+    two_stages<REV, true, true>(x, b1, b2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k & 1)
+            mp.b_odd[16 * k] = x[k];
+        else
+            mp.b_even[16 * k] = x[k];
+    }
+    __syncthreads();
+    {
+        uint32_t cx = mp.c_x;
+        asm volatile("" : "+v"(cx));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(&lds[mp.c_base + 2 * (i ^ cx)]);
+            x[2 * i] = float2{ v.x, v.y };
+            x[2 * i + 1] = float2{ v.z, v.w };
+        }
+    }
+    __syncthreads(); // every read of the tile is done: the next transform may overwrite it
+    two_stages<REV, false, false>(x, a1, a2);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                               const float2 *__restrict__ h, uint64_t batch)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[4096];
+    const uint32_t t = threadIdx.x;
+    float2 wA1[3], wA2[3], wB1[3], wB2[3];
+    const uint32_t rr = t & 15, b = t >> 4;
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        wA1[r - 1] = tw[r * t];
+        wA2[r - 1] = tw[4 * r * t];
+        wB1[r - 1] = tw[16 * r * rr];
+        wB2[r - 1] = tw[64 * r * rr];
+    }
+    lds_map mp;
+    const uint32_t xb = rev4bits(b) << 1;
+    const uint32_t b_base = 256 * b + (rr ^ (xb & 15));
+    const uint32_t b_flip = (xb >> 4) & 1;
+    mp.b_even = lds + b_base + 16 * b_flip;
+    mp.b_odd = lds + b_base - 16 * b_flip;
+    const uint32_t m = ((t & 3) << 6) | (((t >> 2) & 3) << 4) | (((t >> 4) & 3) << 2) | (t >> 6);
+    const uint32_t xc = rev4bits(m >> 4) << 1;
+    mp.c_base = 256 * (m >> 4) + 16 * ((m & 15) ^ (xc >> 4));
+    mp.c_x = (xc >> 1) & 7;
+    mp.t = t;
+
+    for (uint64_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        float2 x[16], z[16];
+        const float2 *src = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = gload<NT>(src + 256 * k);
+        fft4096_in_regs<false>(x, lds, mp, wA1, wA2, wB1, wB2);
+        // x[k] = X[t + 256 j], j = 4 (k & 3) + (k >> 2): multiply by H[t + 256 j] and renumber so that
+        // z[j] is element t + 256 j of the spectrum -- the input layout of the transform's first pass
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = 4 * (k & 3) + (k >> 2);
+            z[j] = cmul(x[k], h[t + 256 * j]);
+        }
+        fft4096_in_regs<true>(z, lds, mp, wA1, wA2, wB1, wB2);
+        float2 *dst = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float2 v = z[k];
+            v.x *= 1.0f / 4096.0f; // reverse_fft::ScaleValues, fft.h:128-132
+            v.y *= 1.0f / 4096.0f;
+            gstore<NT>(dst + 256 * (4 * (k & 3) + (k >> 2)), v);
+        }
+    }
+}
+
 int cu_count()
 {
     static int cached = 0;
@@ -320,6 +435,22 @@ constexpr variant_desc kVariants[] = {
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
+
+int launch_fft4096_conv_f32(void *data, const void *tw, const void *h, uint64_t batch, void *stream)
+{
+    if (batch == 0)
+        return SDSP_HIP_OK;
+    if (batch > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((sdsp_fft4096_conv_f32<true>), dim3((uint32_t)batch), dim3(256), 0, s,
+                       reinterpret_cast<float2 *>(data), reinterpret_cast<const float2 *>(tw),
+                       reinterpret_cast<const float2 *>(h), batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft4096 conv launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 
 const char *fft4096_kernel_name(int variant)
 {

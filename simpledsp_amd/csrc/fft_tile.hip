@@ -14,6 +14,8 @@
 // touch); the tuned kernel for the headline shape lives in fft4096.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
@@ -195,6 +197,34 @@ int launch_one(const tile_dev_args &p, uint64_t n_tiles, size_t lds, hipStream_t
     return SDSP_HIP_OK;
 }
 } // namespace
+
+namespace
+{
+template <typename C> __global__ __launch_bounds__(256) void sdsp_pointwise_mul_kernel(C *data, const C *h, uint32_t n, uint64_t total)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256)
+        data[i] = cmul(data[i], h[i & (n - 1)]); // n is a power of two
+}
+} // namespace
+
+int launch_pointwise_mul(int precision, void *data, const void *h, uint32_t n, uint64_t batch, void *stream)
+{
+    const uint64_t total = (uint64_t)n * batch;
+    if (total == 0)
+        return SDSP_HIP_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 16u);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (precision == SDSP_HIP_F64)
+        hipLaunchKernelGGL(sdsp_pointwise_mul_kernel<double2>, dim3(blocks), dim3(256), 0, s,
+                           reinterpret_cast<double2 *>(data), reinterpret_cast<const double2 *>(h), n, total);
+    else
+        hipLaunchKernelGGL(sdsp_pointwise_mul_kernel<float2>, dim3(blocks), dim3(256), 0, s,
+                           reinterpret_cast<float2 *>(data), reinterpret_cast<const float2 *>(h), n, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("pointwise launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 
 size_t fft_tile_lds_bytes(int precision, uint32_t n, uint32_t pitch)
 {

@@ -132,6 +132,18 @@ class FftPlan:
         self.exec_ptr(x.data_ptr(), x.numel() // self.n, stream)
         return x
 
+    def convolve(self, x, h):
+        """Fast convolution: x <- IFFT(FFT(x) * h) per transform, in place.  x: contiguous
+        device tensor (..., n); h: device tensor (n,) -- the frequency response.  Needs a forward plan."""
+        import torch
+        if _torch_dtypes().get(x.dtype) != self.precision or h.dtype != x.dtype or not x.is_cuda or not h.is_cuda:
+            raise ValueError("convolve needs device tensors of the plan's complex dtype")
+        if not x.is_contiguous() or not h.is_contiguous() or x.shape[-1] != self.n or h.numel() != self.n:
+            raise ValueError("convolve needs contiguous x (..., n) and h (n,)")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        L.check(self._lib.sdsp_hip_fft_convolve(self._h, x.data_ptr(), h.data_ptr(), x.numel() // self.n, stream))
+        return x
+
     def exec_host(self, a: np.ndarray) -> np.ndarray:
         """In place on a C-contiguous numpy array (..., n): H2D, transform, D2H."""
         want = np.complex128 if self.precision == L.F64 else np.complex64

@@ -218,6 +218,35 @@ def test_fft1m_chunking_and_two_stream_variants_agree(sd, torch_cuda, oracle):
             assert torch.equal(first, y), variant
 
 
+@pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
+                                                     (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2)])
+def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
+    """x <- IFFT(FFT(x) .* H).  Checker: the reference's own composition
+    fft_radix<forward>(x); x *= H; fft_radix<reverse_fft>(x) through the oracle, in double."""
+    torch = torch_cuda
+    prec = sd.F32 if precision == "f32" else sd.F64
+    cdt = np.complex64 if prec == sd.F32 else np.complex128
+    rng = np.random.default_rng(n + batch)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(cdt)
+    h = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+    spec = oracle.fft(x.astype(np.complex128), radix) * h.astype(np.complex128)
+    want = oracle.fft(spec, radix, True)
+    plan = sd.FftPlan(n, radix, sd.forward_fft, prec, max_batch=batch)
+    tol = 2e-6 if prec == sd.F32 else 8 * n * EPS64  # two transforms and a product
+    outs = []
+    for variant in ((0, 1) if (n, radix, prec) == (4096, 4, sd.F32) else (0,)):
+        plan.set_variant(variant)  # 4096/r4/f32: 0 = fused single kernel, 1 = three launches
+        d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
+        plan.convolve(d, hd)
+        torch.cuda.synchronize()
+        outs.append(d.cpu().numpy())
+        assert rel_max_err(outs[-1], want) < tol, (variant, rel_max_err(outs[-1], want))
+    if len(outs) == 2:
+        assert rel_max_err(outs[0], outs[1]) < 1e-6
+    with pytest.raises(sd.SdspHipError):
+        sd.FftPlan(n, radix, sd.reverse_fft, prec).convolve(torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda())
+
+
 def test_plan_twiddles_are_the_rounded_reference_row(sd, torch_cuda, fft_golden):
     # a4: the HBM-resident table equals the reference's last table row rounded once to fp32
     plan = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32)
