@@ -127,7 +127,17 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r4_f32(a, p->variant, stream);
     }
 
-    if (p->path == PATH_REG && p->variant < 2) {
+    if (p->path == PATH_REG && p->variant == 0 && p->n == 4096 && p->radix == 2) {
+        fft4096_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.batch = batch;
+        a.scale = 1.0f / 4096.0f;
+        a.reverse = rev;
+        return launch_fft4096_r2_f32(a, stream);
+    }
+
+    if (p->path == PATH_REG && p->variant < 3) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->tw;
@@ -136,7 +146,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.batch = batch;
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
-        a.nontemporal = p->variant == 0;
+        a.nontemporal = p->variant != 1; // 0 (and 2 at n = 4096 radix 2, where 0 is the tuned kernel)
         return launch_fft_reg_f32(a, stream);
     }
 
@@ -591,8 +601,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = fft4096_kernel_name(p->variant);
     if (p->path == PATH_FFT1M && p->variant < 8)
         name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
-    if (p->path == PATH_REG && p->variant < 2)
-        name = "sdsp_fft_reg_kernel";
+    if (p->path == PATH_REG && p->variant < 3)
+        name = (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

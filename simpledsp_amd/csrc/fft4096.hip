@@ -23,6 +23,7 @@
 // HBM-bound by design: 64 KiB of traffic against ~250 kflop per transform.  No MFMA.
 #include <hip/hip_runtime.h>
 
+#include "fft_passes.h"
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
@@ -389,6 +390,87 @@ __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sdsp::fft_radix2<T,4096> (fft.h:258-299) with the same machinery: twelve radix-2 DIF stages as three
+// register passes of four stages (pair distances 2048..256, 128..16, 8..1), the same in-place LDS
+// tile and XOR swizzle (the bank analysis carries over to the bit-reversed block assignment), four
+// thread twiddles per pass instead of six.  The bit reversal (fft.h:269-273) is folded into the last
+// pass's assignment: thread t takes block bit_reverse8(t), whose outputs land at t + 256*bit_reverse4(k).
+template <bool REV, bool NT>
+__global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                              uint64_t batch, float scale)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[4096];
+    const uint32_t t = threadIdx.x;
+    const uint32_t rr = t & 15, b = t >> 4;
+    float2 wA[4], wB[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        wA[j] = tw[t << j];         // stage j of pass A: W_{8192 >> j ... } = W_4096^(t 2^j)
+        wB[j] = tw[(16 * rr) << j]; // pass B: W_4096^(16 rr 2^j)
+    }
+    const uint32_t xb = rev4bits(b) << 1;
+    const uint32_t b_base = 256 * b + (rr ^ (xb & 15));
+    const uint32_t b_flip = (xb >> 4) & 1;
+    float2 *const lds_b_even = lds + b_base + 16 * b_flip;
+    float2 *const lds_b_odd = lds + b_base - 16 * b_flip;
+    const uint32_t m = __brev(t) >> 24; // bit_reverse8(t)
+    const uint32_t xc = rev4bits(m >> 4) << 1;
+    const uint32_t c_base = 256 * (m >> 4) + 16 * ((m & 15) ^ (xc >> 4));
+    const uint32_t c_x = (xc >> 1) & 7;
+
+    for (uint64_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        float2 x[16];
+        const float2 *src = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = gload<NT>(src + 256 * k);
+        passes::r2_pass<REV, true, 0>::run(x, wA);
+        {
+            uint32_t ta = t;
+            asm volatile("" : "+v"(ta));
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                lds[256 * k + (ta ^ ((__brev((uint32_t)k) >> 28) << 1))] = x[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            x[k] = (k & 1) ? lds_b_odd[16 * k] : lds_b_even[16 * k];
+        passes::r2_pass<REV, true, 0>::run(x, wB);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k & 1)
+                lds_b_odd[16 * k] = x[k];
+            else
+                lds_b_even[16 * k] = x[k];
+        }
+        __syncthreads();
+        {
+            uint32_t cx = c_x;
+            asm volatile("" : "+v"(cx));
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 v = *reinterpret_cast<const float4 *>(&lds[c_base + 2 * (i ^ cx)]);
+                x[2 * i] = float2{ v.x, v.y };
+                x[2 * i + 1] = float2{ v.z, v.w };
+            }
+        }
+        __syncthreads();
+        passes::r2_pass<REV, false, 0>::run(x, wA);
+        float2 *dst = data + f * 4096 + t;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float2 v = x[k];
+            if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+                v.x *= scale;
+                v.y *= scale;
+            }
+            gstore<NT>(dst + 256 * (int)(__brev((uint32_t)k) >> 28), v);
+        }
+    }
+}
+
 int cu_count()
 {
     static int cached = 0;
@@ -435,6 +517,25 @@ constexpr variant_desc kVariants[] = {
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
+
+int launch_fft4096_r2_f32(const fft4096_args &a, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    if (a.batch > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float2 *d = reinterpret_cast<float2 *>(a.data);
+    const float2 *w = reinterpret_cast<const float2 *>(a.tw);
+    if (a.reverse)
+        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<true, true>), dim3((uint32_t)a.batch), dim3(256), 0, s, d, w, a.batch, a.scale);
+    else
+        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<false, true>), dim3((uint32_t)a.batch), dim3(256), 0, s, d, w, a.batch, a.scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft4096 r2 launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 
 int launch_fft4096_conv_f32(void *data, const void *tw, const void *h, uint64_t batch, void *stream)
 {

@@ -61,6 +61,7 @@ struct fft4096_args {
 int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
 const char *fft4096_kernel_name(int variant);
 int fft4096_num_variants();
+int launch_fft4096_r2_f32(const fft4096_args &a, void *stream); // tuned radix-2 sibling
 // fused y = IFFT(FFT(x) .* h), n = 4096, f32; tw = FORWARD twiddle row
 int launch_fft4096_conv_f32(void *data, const void *tw, const void *h, uint64_t batch, void *stream);
 // data[b][i] *= h[i] (generic three-launch convolution path)

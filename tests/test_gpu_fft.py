@@ -127,9 +127,9 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        assert plan.info.kernel.decode() == "sdsp_fft_reg_kernel"
+        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_reg_kernel")
         outs = []
-        for variant in (0, 1, 99):  # streaming / default cache policy / coverage kernel
+        for variant in (0, 1, 99) if (n, radix) != (4096, 2) else (2, 1, 99, 0):  # streaming / default policy / coverage kernel / tuned r2
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector
@@ -139,6 +139,22 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
             assert rel_max_err(outs[-1], want) < TOL32, (n, radix, rev, variant, rel_max_err(outs[-1], want))
             assert bool((guard == 7.0 + 3.0j).all())
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("batch", [1, 3, 255, 2049])
+def test_fft4096_radix2_tuned_kernel(sd, torch_cuda, oracle, batch):
+    torch = torch_cuda
+    rng = np.random.default_rng(40 + batch)
+    x = (rng.standard_normal((batch, 4096)) + 1j * rng.standard_normal((batch, 4096))).astype(np.complex64)
+    pick = rng.choice(batch, size=min(batch, 6), replace=False)
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        plan = sd.FftPlan(4096, 2, T, sd.F32, max_batch=batch)
+        assert plan.info.kernel.decode() == "sdsp_fft4096_r2_f32"
+        d = torch.from_numpy(x).cuda()
+        plan.exec(d)
+        torch.cuda.synchronize()
+        want = oracle.fft(x[pick].astype(np.complex128), 2, rev)
+        assert rel_max_err(d.cpu().numpy()[pick], want) < TOL32
 
 
 def test_n1_is_identity(sd, torch_cuda):
