@@ -1,9 +1,9 @@
-// fft_reg.hip -- register-pass FFT family for gfx950: f32, N = 16 .. 4096, radix-2 stages
+// fft_reg.hip -- register-pass FFT family for gfx950: f32, N = 16 .. 16384, radix-2 stages
 // (sdsp::fft_radix2, fft.h:258-299) or radix-4 stages (sdsp::fft_radix4, fft.h:301-360), forward
 // or reverse.  Fast path for every batched size the tuned N=4096 radix-4 kernel does not cover.
 //
 // A 256-thread workgroup owns 4096 complex points = 4096/N consecutive transforms (32 KiB of the
-// batch, contiguous in HBM):
+// batch, contiguous in HBM); for N = 8192 / 16384 a 512- / 1024-thread workgroup owns one transform:
 //   1. the 32 KiB are copied HBM -> LDS with 16-byte lanes (fully coalesced, any N);
 //   2. ceil(log2 N / 4) passes: a thread pulls 16 points (stride N/16^(i+1)) of one transform from
 //      LDS into registers, runs four radix-2 DIF stages -- or two radix-4 DIF stages -- on them and
@@ -96,8 +96,9 @@ template <bool NT> __device__ __forceinline__ void gstore16(float4 *p, float4 a)
     }
 }
 
-constexpr int kPoints = 4096;                  // complex points per workgroup
-constexpr int kSlots = kPoints + kPoints / 16; // one padding slot per 16
+// complex points per workgroup: 4096 (256 threads), or one whole transform for N = 8192 / 16384
+// (512 / 1024 threads); LDS holds them with one padding slot per 16
+constexpr int points_for(int log2n) { return log2n > 12 ? (1 << log2n) : 4096; }
 __device__ __forceinline__ uint32_t slot(uint32_t p) { return p + (p >> 4); }
 
 // reversed index of q within an N-point transform: bit reversal (radix 2) or base-4 digit reversal
@@ -110,16 +111,20 @@ template <int RADIX, int LOG2N> __device__ __forceinline__ uint32_t reversed(uin
 }
 
 template <int RADIX, int LOG2N, bool REV, bool NT>
-__global__ __launch_bounds__(256) void sdsp_fft_reg_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                           uint64_t batch, float scale)
+__global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(float2 *__restrict__ data,
+                                                                             const float2 *__restrict__ tw,
+                                                                             uint64_t batch, float scale)
 {
     constexpr int N = 1 << LOG2N;
+    constexpr int kPoints = points_for(LOG2N);
+    constexpr int THREADS = kPoints / 16;
     constexpr int T = N / 16;             // threads per transform
     constexpr int G = kPoints / N;        // transforms per workgroup
     constexpr int P = (LOG2N + 3) / 4;    // register passes
     constexpr int LAST = LOG2N - 4 * (P - 1); // radix-2 stages left for the last pass (1..4)
     static_assert(RADIX == 2 || (LOG2N % 2 == 0), "radix 4 needs a power of 4");
-    __shared__ __attribute__((aligned(16))) float2 lds[kSlots];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_reg_smem[];
+    float2 *lds = reinterpret_cast<float2 *>(sdsp_fft_reg_smem); // kPoints + kPoints/16 slots
 
     const uint32_t tid = threadIdx.x;
     const uint64_t first = (uint64_t)blockIdx.x * G;             // first transform of this workgroup
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_reg_kernel(float2 *__restrict__ 
     // 1. HBM -> LDS, 16 bytes per lane (two points), linear
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const uint32_t e = 2 * (tid + 256 * k);
+        const uint32_t e = 2 * (tid + THREADS * k);
         if (e < live) {
             const float4 v = gload16<NT>(reinterpret_cast<const float4 *>(base + e));
             lds[slot(e)] = float2{ v.x, v.y };
@@ -184,11 +189,13 @@ __global__ __launch_bounds__(256) void sdsp_fft_reg_kernel(float2 *__restrict__ 
         run_pass(std::integral_constant<int, 1>{});
     if constexpr (P > 2)
         run_pass(std::integral_constant<int, 2>{});
+    if constexpr (P > 3)
+        run_pass(std::integral_constant<int, 3>{});
 
     // 3. LDS -> HBM: X[q] sits at position reversed(q) of its transform
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const uint32_t e = 2 * (tid + 256 * k);
+        const uint32_t e = 2 * (tid + THREADS * k);
         if (e < live) {
             const uint32_t tb = e & ~(uint32_t)(N - 1), q = e & (N - 1);
             float2 a = lds[slot(tb + reversed<RADIX, LOG2N>(q))];
@@ -204,25 +211,40 @@ __global__ __launch_bounds__(256) void sdsp_fft_reg_kernel(float2 *__restrict__ 
     }
 }
 
+template <int RADIX, int LOG2N, bool REV, bool NT>
+void launch_one(const fft_reg_args &a, dim3 grid, hipStream_t s)
+{
+    constexpr int kPoints = points_for(LOG2N);
+    constexpr size_t lds = (size_t)(kPoints + kPoints / 16) * sizeof(float2);
+    auto kern = sdsp_fft_reg_kernel<RADIX, LOG2N, REV, NT>;
+    if constexpr (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kPoints / 16), lds, s, reinterpret_cast<float2 *>(a.data),
+                       reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale);
+}
+
 template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t s)
 {
-    constexpr int G = kPoints >> LOG2N;
+    constexpr int G = points_for(LOG2N) >> LOG2N;
     const uint64_t blocks = (a.batch + G - 1) / G;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    float2 *d = reinterpret_cast<float2 *>(a.data);
-    const float2 *w = reinterpret_cast<const float2 *>(a.tw);
-    const dim3 grid((uint32_t)blocks), block(256);
+    const dim3 grid((uint32_t)blocks);
     if (a.nontemporal) {
         if (a.reverse)
-            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, true, true>), grid, block, 0, s, d, w, a.batch, a.scale);
+            launch_one<RADIX, LOG2N, true, true>(a, grid, s);
         else
-            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, false, true>), grid, block, 0, s, d, w, a.batch, a.scale);
+            launch_one<RADIX, LOG2N, false, true>(a, grid, s);
     } else {
         if (a.reverse)
-            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, true, false>), grid, block, 0, s, d, w, a.batch, a.scale);
+            launch_one<RADIX, LOG2N, true, false>(a, grid, s);
         else
-            hipLaunchKernelGGL((sdsp_fft_reg_kernel<RADIX, LOG2N, false, false>), grid, block, 0, s, d, w, a.batch, a.scale);
+            launch_one<RADIX, LOG2N, false, false>(a, grid, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -233,7 +255,7 @@ template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t 
 
 bool fft_reg_supports(uint32_t n, int radix)
 {
-    if (n < 16 || n > 4096 || !sdsp_hip_is_power_of_2(n))
+    if (n < 16 || n > 16384 || !sdsp_hip_is_power_of_2(n))
         return false;
     return radix == 2 || (radix == 4 && sdsp_hip_is_power_of_4(n));
 }
@@ -255,6 +277,8 @@ int launch_fft_reg_f32(const fft_reg_args &a, void *stream)
         case 10: return launch_n<2, 10>(a, s);
         case 11: return launch_n<2, 11>(a, s);
         case 12: return launch_n<2, 12>(a, s);
+        case 13: return launch_n<2, 13>(a, s);
+        case 14: return launch_n<2, 14>(a, s);
         default: break;
         }
     } else if (a.radix == 4) {
@@ -264,6 +288,7 @@ int launch_fft_reg_f32(const fft_reg_args &a, void *stream)
         case 8: return launch_n<4, 8>(a, s);
         case 10: return launch_n<4, 10>(a, s);
         case 12: return launch_n<4, 12>(a, s);
+        case 14: return launch_n<4, 14>(a, s);
         default: break;
         }
     }

@@ -118,7 +118,8 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
 
 
 @pytest.mark.parametrize("n,radix,batch", [(16, 2, 1), (16, 4, 300), (32, 2, 129), (64, 4, 1000), (128, 2, 33), (256, 4, 17),
-                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (2048, 2, 3), (4096, 2, 5)])
+                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (2048, 2, 3), (4096, 2, 5),
+                                           (8192, 2, 3), (16384, 2, 2), (16384, 4, 3)])
 def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
     # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
     torch = torch_cuda
