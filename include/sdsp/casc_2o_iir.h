@@ -296,6 +296,14 @@ public:
         ensure_state();
         detail::check(sdsp_hip_iir_process(m_plan, device_data, m_channels, samples, stride, m_state, stream));
     }
+    // the sample-major "wire" layout: sample s of channel c at device_data[s*stride + c];
+    // no transpose, bit-identical to process() on the transposed data
+    void process_interleaved(real_t *device_data, std::uint64_t samples, std::uint64_t stride, void *stream = nullptr)
+    {
+        ensure_plan();
+        ensure_state();
+        detail::check(sdsp_hip_iir_process_interleaved(m_plan, device_data, m_channels, samples, stride, m_state, stream));
+    }
     // host pointer convenience: channels x samples, contiguous
     void process_host(real_t *host_data, std::uint64_t samples)
     {

@@ -181,6 +181,14 @@ public:
         std::lock_guard<std::mutex> lock(m_h->mutex());
         detail::check(sdsp_hip_fft_exec_host(m_h->get(), host_data, batch));
     }
+    // fast convolution: data <- IFFT(FFT(data) .* h) per transform, in place; needs a
+    // FORWARD plan; device pointers; h = n complex values (frequency response, natural order).
+    // One fused kernel at n = 4096 / radix 4 / float.
+    void convolve(std::complex<real_t> *device_data, const std::complex<real_t> *device_h, std::uint64_t batch,
+                  void *stream = nullptr)
+    {
+        detail::check(sdsp_hip_fft_convolve(m_h->get(), device_data, device_h, batch, stream));
+    }
     sdsp_hip_fft_plan *native_handle() const noexcept { return m_h->get(); }
 
 private:

@@ -290,6 +290,23 @@ def test_host_pointer_and_sharded_entry_points(sd, torch_cuda, oracle):
     assert sd.load().sdsp_hip_fft_exec(plan._h, None, 0, None) == 0  # empty batch is a no-op
 
 
+def test_sharded_entry_with_several_plans(sd, torch_cuda, oracle):
+    # contiguous batch ranges, one host thread + plan per shard, no collective.  With one
+    # GPU the shards all live on device 0; the partitioning and threading are what is exercised.
+    from simpledsp_amd import _lib as L
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((11, 4096)) + 1j * rng.standard_normal((11, 4096))).astype(np.complex64)
+    want = oracle.fft(x.astype(np.complex128), 4)
+    plans = [sd.FftPlan(4096, 4, sd.forward_fft, sd.F32, max_batch=11) for _ in range(3)]
+    arr = (C.c_void_p * 3)(*[p._h for p in plans])
+    y = x.copy()
+    L.check(sd.load().sdsp_hip_fft_exec_sharded(arr, 3, y.ctypes.data, 11))
+    assert rel_max_err(y, want) < TOL32
+    bad = sd.FftPlan(1024, 4, sd.forward_fft, sd.F32)
+    arr2 = (C.c_void_p * 2)(plans[0]._h, bad._h)
+    assert sd.load().sdsp_hip_fft_exec_sharded(arr2, 2, y.ctypes.data, 11) == L.ERR_INVALID_ARG
+
+
 @pytest.mark.parametrize("batch", [65536])
 def test_baseline_config2_full_size_properties(sd, torch_cuda, oracle, batch):
     """BASELINE config 2 at full size (65536 x 4096 f32, 2 GiB): size-independent properties +
