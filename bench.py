@@ -220,7 +220,7 @@ def main():
     torch.cuda.set_device(dev)
     sd.load()
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SDSP_BENCH_FORCE_DIST") == "1":  # the env var lets a 1-GPU box rehearse the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

@@ -27,7 +27,10 @@ def env_world() -> Tuple[int, int, int]:
 def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None], dist=None,
                 device=None) -> float:
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + sync on both sides.
-    Returns the MAX over ranks of the wall time of the K steps (seconds)."""
+    Returns the MAX over ranks of the wall time of the K steps (seconds).  All ranks leave the opening
+    barrier together; each stops its clock when its own K steps have drained (synchronize), then joins
+    the closing barrier -- so the maximum is the whole job's time without charging the barrier's own
+    latency (~2 ms for RCCL) to the steps."""
     import torch
     for _ in range(warmup):
         step()
@@ -39,10 +42,10 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callabl
     for _ in range(steps):
         step()
     sync()
+    wall = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     sync()
-    wall = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
