@@ -299,17 +299,32 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
 
     const int piece = lane % NV, sub = lane / NV;
     const uint64_t n_super = (p.samples + SUBS * T - 1) / (SUBS * T);
+    // interior workgroups (all 64 channels exist) take an unguarded path for their full super-tiles:
+    // one per-lane base pointer + wave-uniform offsets, no per-access predicates
+    const bool interior = ch0 + 64 <= p.channels;
+    R *const lane_base = p.data + (ch0 + sub) * p.stride + (uint64_t)piece * EPV;
+    const uint64_t group_step = (uint64_t)RPI * p.stride; // elements between row groups
     for (uint64_t st = 0; st < n_super; st++) {
-        V stage[SUBS * NV]; // register 4*i + j: rows 8i..8i+7, sub-tile j
+        V stage[SUBS * NV]; // register SUBS*i + j: rows 8i..8i+7, sub-tile j
+        const bool full = interior && (st + 1) * SUBS * T <= p.samples;
+        R *const tile_base = lane_base + st * SUBS * T;
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+            for (int i = 0; i < NV; i++)
 #pragma unroll
-            for (int j = 0; j < SUBS; j++) {
-                const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
-                stage[SUBS * i + j] = V{};
-                if (ch < p.channels && s0 < p.samples)
-                    stage[SUBS * i + j] = gload16<R, NT>(p.data + ch * p.stride + s0);
+                for (int j = 0; j < SUBS; j++)
+                    stage[SUBS * i + j] = gload16<R, NT>(tile_base + i * group_step + j * T);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+#pragma unroll
+                for (int j = 0; j < SUBS; j++) {
+                    const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
+                    stage[SUBS * i + j] = V{};
+                    if (ch < p.channels && s0 < p.samples)
+                        stage[SUBS * i + j] = gload16<R, NT>(p.data + ch * p.stride + s0);
+                }
             }
         }
 #pragma unroll
@@ -350,14 +365,22 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
                 stage[SUBS * i + j] = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
             __syncthreads();
         }
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+            for (int i = 0; i < NV; i++)
 #pragma unroll
-            for (int j = 0; j < SUBS; j++) {
-                const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
-                if (ch < p.channels && s0 < p.samples)
-                    gstore16<R, NT>(p.data + ch * p.stride + s0, stage[SUBS * i + j]);
+                for (int j = 0; j < SUBS; j++)
+                    gstore16<R, NT>(tile_base + i * group_step + j * T, stage[SUBS * i + j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
+#pragma unroll
+                for (int j = 0; j < SUBS; j++) {
+                    const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
+                    if (ch < p.channels && s0 < p.samples)
+                        gstore16<R, NT>(p.data + ch * p.stride + s0, stage[SUBS * i + j]);
+                }
             }
         }
     }
@@ -472,7 +495,7 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
     const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(R)) % 16 == 0) &&
                          ((a.samples * sizeof(R)) % 16 == 0);
     // variants (identical arithmetic, bit-identical results):
-    //   0 super-tile (default)                 1 super-tile, streaming (non-temporal) accesses
+    //   0 super-tile, streaming accesses (default)   1 super-tile, default cache policy
     //   2 tiled 128-byte rows, streaming       3 direct (any alignment)       4 tiled 256-byte rows
     //   5 super-tile of 3 sub-tiles (384 B bursts, 3 waves/SIMD)   6 of 2 sub-tiles (256 B, 4 waves/SIMD)
     if (variant != 3 && !aligned)
@@ -485,11 +508,11 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
         if (blocks > 0x7fffffffull)
             return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
         const size_t lds = 64 * (128 + 16);
-        if (variant == 0) // measured: default policy 5.12 TB/s vs streaming 5.03 TB/s (f32, round 1)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+        if (variant == 0) // measured (f32, round 1): streaming 5.58 TB/s vs default policy 5.29 TB/s
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else if (variant == 1)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else if (variant == 5)
             hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 3>), dim3((uint32_t)blocks), dim3(64), lds,

@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void iir_shape(float4 *p, size_t rows, size_t 
 template <bool NT>
 __global__ __launch_bounds__(64) void iir_shape_rg(float4 *p, size_t rows, size_t row_vecs, float s)
 {
+    extern __shared__ float4 occupancy_limiter[]; // dynamic LDS request only throttles waves per CU
+    if (s == 12345.f) p[0] = occupancy_limiter[threadIdx.x];
     const int lane = threadIdx.x;
     const size_t r0 = (size_t)blockIdx.x * 64;
     if (r0 >= rows) return;
@@ -254,8 +256,13 @@ int main()
         report("iir shape 256 B/row/step, nt", time_ms([&] { iir_shape<256, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
         report("iir shape 512 B/row/step, plain", time_ms([&] { iir_shape<512, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
         report("iir shape 512 B/row/step, nt", time_ms([&] { iir_shape<512, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
-        report("iir shape 4x128 B back-to-back, 1-wave wg, plain", time_ms([&] { iir_shape_rg<false><<<(int)(rows / 64), 64>>>((float4 *)d, rows, row_vecs, 1.0f); }));
-        report("iir shape 4x128 B back-to-back, 1-wave wg, nt", time_ms([&] { iir_shape_rg<true><<<(int)(rows / 64), 64>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        for (int waves_per_cu : {32, 16, 12, 8, 4}) {
+            const size_t lds = waves_per_cu >= 32 ? 0 : (160 * 1024 / waves_per_cu) & ~1023u;
+            char nm[96];
+            snprintf(nm, sizeof nm, "iir shape 4x128 B b2b, <=%d waves/CU, plain", waves_per_cu);
+            hipFuncSetAttribute((const void *)iir_shape_rg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            report(nm, time_ms([&] { iir_shape_rg<false><<<(int)(rows / 64), 64, lds>>>((float4 *)d, rows, row_vecs, 1.0f); }));
+        }
         report("iir shape 1024 B/row/step, plain", time_ms([&] { iir_shape<1024, false><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
         report("iir shape 1024 B/row/step, nt", time_ms([&] { iir_shape<1024, true><<<blocks, 256>>>((float4 *)d, rows, row_vecs, 1.0f); }));
     }
