@@ -30,8 +30,10 @@ def short(name: str) -> str:
 
 
 def one(pattern):
-    g = glob.glob(str(src / pattern))
-    return g[0] if g else None
+    # gpurun MERGES new output into the local folder, so files of earlier runs (other PIDs) linger:
+    # always take the newest match
+    g = sorted(glob.glob(str(src / pattern)), key=lambda f: Path(f).stat().st_mtime)
+    return g[-1] if g else None
 
 
 lines = [f"# profile {tag}", ""]
@@ -88,8 +90,11 @@ for k in traffic:
     traffic[k]["launches_per_step"] = LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
 alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
 if alg:
-    lines += ["", f"algorithmic bytes per launch: {alg} -> traffic / algorithmic = "
-              + ", ".join(f"{v['hbm_bytes_per_launch']/alg:.4f}" for v in traffic.values())]
+    per_step = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in traffic.values())
+    n_inst = max(1, len(traffic) // max(1, len({k.split("<")[0] for k in traffic})))  # fwd/rev instantiations
+    lines += ["", f"algorithmic bytes per bench step: {alg}; fabric traffic per step (all kernels, launches per step "
+              f"accounted, forward/reverse instantiations averaged): {per_step / n_inst:.4g} -> "
+              f"traffic / algorithmic = {per_step / n_inst / alg:.4f}"]
 (out / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
 
 tj = out / "traffic.json"
