@@ -442,6 +442,13 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
     R *col = p.data + c0;
     V cur[U], nxt[U];
     auto fetch = [&](V (&dst)[U], uint64_t s0) {
+        if (s0 + U <= p.samples) { // whole batch inside the stream: no per-row predicates
+            R *row = col + s0 * p.stride;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                dst[u] = gload_cv<R, VEC, NT>(row + u * p.stride);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             dst[u] = V{};
@@ -453,13 +460,24 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
     for (uint64_t s0 = 0; s0 < p.samples; s0 += U) {
         if (s0 + U < p.samples)
             fetch(nxt, s0 + U);
+        if (s0 + U <= p.samples) {
+            R *row = col + s0 * p.stride;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (s0 + u < p.samples) {
+            for (int u = 0; u < U; u++) {
 #pragma unroll
                 for (int e = 0; e < VEC; e++)
                     cur[u].v[e] = cascade_step<R, KIND, M>(cur[u].v[e], p, y1[e], y2[e], y3[e]);
-                gstore_cv<R, VEC, NT>(col + (s0 + u) * p.stride, cur[u]);
+                gstore_cv<R, VEC, NT>(row + u * p.stride, cur[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (s0 + u < p.samples) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++)
+                        cur[u].v[e] = cascade_step<R, KIND, M>(cur[u].v[e], p, y1[e], y2[e], y3[e]);
+                    gstore_cv<R, VEC, NT>(col + (s0 + u) * p.stride, cur[u]);
+                }
             }
         }
 #pragma unroll
