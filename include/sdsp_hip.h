@@ -123,6 +123,21 @@ int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void
 int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *plan, void *data, const void *h, uint64_t batch,
                           void *stream);
 
+/*
+ * Real-input packing, SURVEY 8(f)-3.  Every reference test feeds REAL signals through the complex
+ * transform (testFFT.cpp:23-25,84-90); a plan made here moves half the bytes: n_real real samples
+ * are transformed as n_real/2 complex points and split / merged on chip.
+ *   direction FORWARD: data = batch x n_real floats in, batch x n_real/2 complex out, in place:
+ *     out[k] = X[k] for 0 < k < n_real/2 (the spectrum of the real signal, same values the complex
+ *     transform would give), out[0] = (X[0], X[n_real/2]) -- both are real; the upper half of the
+ *     spectrum is the conjugate mirror.
+ *   direction REVERSE: the inverse of that (packed half spectrum in, real samples out, 1/N scaled).
+ * f32; radix 2: n_real = 32 .. 32768 a power of 2; radix 4: n_real/2 a power of 4.  Use the plan
+ * with sdsp_hip_fft_exec / _exec_host (batch counts transforms).
+ */
+int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction,
+                              uint64_t max_batch, int device);
+
 typedef struct {
     uint32_t n;
     int radix;

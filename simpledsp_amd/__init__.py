@@ -6,7 +6,7 @@ the library or without a HIP device raises (there is no CPU path here).
 """
 from ._lib import (F32, F64, FORWARD, REVERSE, IIR_GENERIC, IIR_LP, IIR_HP, IIR_BP, FILTER_NONE,
                    FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS, SdspHipError, load)
-from .fft import (FftPlan, fft_radix2, fft_radix4, forward_fft, reverse_fft, log2, log4, isPowerOf2,
+from .fft import (FftPlan, RfftPlan, fft_radix2, fft_radix4, forward_fft, reverse_fft, log2, log4, isPowerOf2,
                   isPowerOf4, digit_reverse, calc_swap_lookup, calc_twiddles, calc_wCoeffs)
 from .iir import casc_2o_iir, casc_2o_iir_lp, casc_2o_iir_hp, casc_2o_iir_bp
 

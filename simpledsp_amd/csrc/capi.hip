@@ -89,6 +89,7 @@ struct sdsp_hip_fft_plan {
     hipStream_t aux_stream = nullptr;
     std::vector<hipEvent_t> events;
     sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
+    int real_mode = 0;                    // 0 complex; 1 real forward; 2 real inverse (n = n_real / 2)
 };
 
 struct sdsp_hip_iir_plan {
@@ -127,7 +128,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r4_f32(a, p->variant, stream);
     }
 
-    if (p->path == PATH_REG && p->variant == 0 && p->n == 4096 && p->radix == 2) {
+    if (p->path == PATH_REG && p->variant == 0 && p->n == 4096 && p->radix == 2 && !p->real_mode) {
         fft4096_args a;
         a.data = data;
         a.tw = p->tw;
@@ -147,8 +148,13 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
         a.nontemporal = p->variant != 1; // 0 (and 2 at n = 4096 radix 2, where 0 is the tuned kernel)
+        a.real_mode = p->real_mode;
+        a.tw2 = p->tw2;
         return launch_fft_reg_f32(a, stream);
     }
+
+    if (p->real_mode)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans have no alternative kernel variant");
 
     if (p->path == PATH_TILE || p->path == PATH_FFT4096 || p->path == PATH_REG) {
         fft_tile_args a{};
@@ -450,6 +456,37 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     return SDSP_HIP_OK;
 }
 
+int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **out, uint32_t n_real, int radix, int direction, uint64_t max_batch,
+                              int device)
+{
+    if (!out)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
+    *out = nullptr;
+    if (!sdsp_hip_is_power_of_2(n_real) || n_real < 32)
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2! (real-input plans: >= 32)");
+    const uint32_t n = n_real / 2;
+    if (radix == 4 && !sdsp_hip_is_power_of_4(n))
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT radix 4 size must be a power of 4! (n_real / 2)");
+    if (radix != 2 && radix != 4)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix must be 2 or 4");
+    if (!fft_reg_supports(n, radix))
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768");
+    sdsp_hip_fft_plan *p = nullptr;
+    if (int rc = sdsp_hip_fft_plan_create(&p, n, radix, direction, SDSP_HIP_F32, max_batch, device))
+        return rc;
+    p->path = PATH_REG; // also at n = 4096 (the tuned complex kernels have no split stage)
+    p->real_mode = direction == SDSP_HIP_FORWARD ? 1 : 2;
+    std::vector<double> w;
+    make_twiddles(n_real, direction, w);
+    if (int rc = upload_twiddles(w, SDSP_HIP_F32, &p->tw2)) {
+        sdsp_hip_fft_plan_destroy(p);
+        return rc;
+    }
+    p->twiddle_bytes += (uint64_t)n_real * 8;
+    *out = p;
+    return SDSP_HIP_OK;
+}
+
 int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
 {
     if (!p)
@@ -593,7 +630,7 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->precision = p->precision;
     info->device = p->device;
     info->hbm_passes = (p->path == PATH_FOUR_STEP || p->path == PATH_FFT1M) ? 2 : 1;
-    info->algorithmic_bytes = 2ull * p->n * esize(p->precision);
+    info->algorithmic_bytes = 2ull * p->n * esize(p->precision); // real plans: n complex = n_real floats, same bytes
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;
     const char *name = "sdsp_fft_tile_kernel";
@@ -602,7 +639,7 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_FFT1M && p->variant < 8)
         name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
     if (p->path == PATH_REG && p->variant < 3)
-        name = (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
+        name = p->real_mode ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

@@ -110,9 +110,19 @@ template <int RADIX, int LOG2N> __device__ __forceinline__ uint32_t reversed(uin
     return r;
 }
 
-template <int RADIX, int LOG2N, bool REV, bool NT>
+// MODE 0: complex transform.  MODE 1 / 2 (real-input packing): the buffer holds 2N REAL
+// samples per transform, reinterpreted as N complex z[m] = x[2m] + i x[2m+1].
+//   MODE 1 (forward): after the passes an in-LDS split turns Z = FFT_N(z) into the first half of the
+//     2N-point spectrum of x:  X[k] = E + T, X[N-k] = conj(E - T), E = (Z[k] + conj(Z[N-k]))/2,
+//     T = -i W_2N^k (Z[k] - conj(Z[N-k]))/2; packed in place: out[0] = (X[0], X[N]) (both real).
+//   MODE 2 (inverse): the packed half-spectrum is merged back (the same algebra inverted) before the
+//     passes; the reverse transform then yields z, i.e. the real samples.
+// Half the HBM bytes of pushing a real signal through the complex transform (what every reference
+// test does, testFFT.cpp:23-25,84-90).  tw2 = W_2N^k, direction-folded like tw.
+template <int RADIX, int LOG2N, bool REV, bool NT, int MODE>
 __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(float2 *__restrict__ data,
                                                                              const float2 *__restrict__ tw,
+                                                                             const float2 *__restrict__ tw2,
                                                                              uint64_t batch, float scale)
 {
     constexpr int N = 1 << LOG2N;
@@ -143,6 +153,27 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
         }
     }
     __syncthreads();
+
+    if constexpr (MODE == 2) {
+        // merge: natural-order packed half-spectrum -> Z (natural order), pairs (k, N-k)
+        for (uint32_t idx = tid; idx < (uint32_t)(kPoints / 2); idx += THREADS) {
+            const uint32_t tb = (idx / (N / 2)) * N, k = idx % (N / 2);
+            if (k == 0) {
+                const float2 x0 = lds[slot(tb)];            // (X[0], X[N]) both real
+                lds[slot(tb)] = float2{ 0.5f * (x0.x + x0.y), 0.5f * (x0.x - x0.y) };
+                const float2 xm = lds[slot(tb + N / 2)];    // X[N/2] = conj(Z[N/2])
+                lds[slot(tb + N / 2)] = float2{ xm.x, -xm.y };
+            } else {
+                const float2 xa = lds[slot(tb + k)], xb = lds[slot(tb + N - k)];
+                const float2 e = float2{ 0.5f * (xa.x + xb.x), 0.5f * (xa.y - xb.y) };  // (Xa + conj Xb)/2
+                const float2 wo = float2{ 0.5f * (xa.x - xb.x), 0.5f * (xa.y + xb.y) }; // (Xa - conj Xb)/2
+                const float2 o = cmul(wo, tw2[k]);                                      // conj(W)·(W·O): tw2 is reverse-folded
+                lds[slot(tb + k)] = float2{ e.x - o.y, e.y + o.x };                     // E + i O
+                lds[slot(tb + N - k)] = float2{ e.x + o.y, o.x - e.y };                 // conj(E - i O)
+            }
+        }
+        __syncthreads();
+    }
 
     // 2. register passes, in place in LDS
     const uint32_t g = tid / T, t = tid % T; // transform within the workgroup, thread within it
@@ -192,6 +223,30 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
     if constexpr (P > 3)
         run_pass(std::integral_constant<int, 3>{});
 
+    if constexpr (MODE == 1) {
+        // split: Z[k] sits at position reversed(k); pairs (k, N-k) are rewritten in place
+        for (uint32_t idx = tid; idx < (uint32_t)(kPoints / 2); idx += THREADS) {
+            const uint32_t tb = (idx / (N / 2)) * N, k = idx % (N / 2);
+            if (k == 0) {
+                const float2 z0 = lds[slot(tb)];
+                lds[slot(tb)] = float2{ z0.x + z0.y, z0.x - z0.y }; // (X[0], X[N])
+                const uint32_t pm = slot(tb + reversed<RADIX, LOG2N>(N / 2));
+                const float2 zm = lds[pm];
+                lds[pm] = float2{ zm.x, -zm.y };                    // X[N/2] = conj(Z[N/2])
+            } else {
+                const uint32_t pa = slot(tb + reversed<RADIX, LOG2N>(k)), pb = slot(tb + reversed<RADIX, LOG2N>(N - k));
+                const float2 za = lds[pa], zb = lds[pb];
+                const float2 e = float2{ 0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y) }; // (Za + conj Zb)/2
+                const float2 d = float2{ 0.5f * (za.x - zb.x), 0.5f * (za.y + zb.y) }; // (Za - conj Zb)/2
+                const float2 wd = cmul(d, tw2[k]);
+                const float2 tt = float2{ wd.y, -wd.x };                               // -i W D
+                lds[pa] = float2{ e.x + tt.x, e.y + tt.y };                            // X[k] = E + T
+                lds[pb] = float2{ e.x - tt.x, tt.y - e.y };                            // X[N-k] = conj(E - T)
+            }
+        }
+        __syncthreads();
+    }
+
     // 3. LDS -> HBM: X[q] sits at position reversed(q) of its transform
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -211,12 +266,12 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
     }
 }
 
-template <int RADIX, int LOG2N, bool REV, bool NT>
+template <int RADIX, int LOG2N, bool REV, bool NT, int MODE>
 void launch_one(const fft_reg_args &a, dim3 grid, hipStream_t s)
 {
     constexpr int kPoints = points_for(LOG2N);
     constexpr size_t lds = (size_t)(kPoints + kPoints / 16) * sizeof(float2);
-    auto kern = sdsp_fft_reg_kernel<RADIX, LOG2N, REV, NT>;
+    auto kern = sdsp_fft_reg_kernel<RADIX, LOG2N, REV, NT, MODE>;
     if constexpr (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -225,7 +280,7 @@ void launch_one(const fft_reg_args &a, dim3 grid, hipStream_t s)
         }
     }
     hipLaunchKernelGGL(kern, grid, dim3(kPoints / 16), lds, s, reinterpret_cast<float2 *>(a.data),
-                       reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale);
+                       reinterpret_cast<const float2 *>(a.tw), reinterpret_cast<const float2 *>(a.tw2), a.batch, a.scale);
 }
 
 template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t s)
@@ -235,16 +290,20 @@ template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t 
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     const dim3 grid((uint32_t)blocks);
-    if (a.nontemporal) {
+    if (a.real_mode == 1) { // real forward: always the forward direction, streaming accesses
+        launch_one<RADIX, LOG2N, false, true, 1>(a, grid, s);
+    } else if (a.real_mode == 2) { // real inverse
+        launch_one<RADIX, LOG2N, true, true, 2>(a, grid, s);
+    } else if (a.nontemporal) {
         if (a.reverse)
-            launch_one<RADIX, LOG2N, true, true>(a, grid, s);
+            launch_one<RADIX, LOG2N, true, true, 0>(a, grid, s);
         else
-            launch_one<RADIX, LOG2N, false, true>(a, grid, s);
+            launch_one<RADIX, LOG2N, false, true, 0>(a, grid, s);
     } else {
         if (a.reverse)
-            launch_one<RADIX, LOG2N, true, false>(a, grid, s);
+            launch_one<RADIX, LOG2N, true, false, 0>(a, grid, s);
         else
-            launch_one<RADIX, LOG2N, false, false>(a, grid, s);
+            launch_one<RADIX, LOG2N, false, false, 0>(a, grid, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -77,6 +77,8 @@ struct fft_reg_args {
     float scale;
     int reverse;
     int nontemporal;
+    int real_mode = 0;         // 0 complex; 1 real forward (split); 2 real inverse (merge): SURVEY 8(f)-3
+    const void *tw2 = nullptr; // real modes: W_{2n}^k
 };
 bool fft_reg_supports(uint32_t n, int radix);
 int launch_fft_reg_f32(const fft_reg_args &a, void *stream);

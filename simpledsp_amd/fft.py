@@ -153,6 +153,38 @@ class FftPlan:
         return a
 
 
+class RfftPlan:
+    """Real-input packing: n_real real samples <-> packed half spectrum, in place.
+
+    forward_fft: float32 (..., n_real) -> the same memory viewed as complex64 (..., n_real/2) with
+    out[..., k] = X[k] (0 < k < n_real/2) and out[..., 0] = X[0] + 1j*X[n_real/2]; reverse_fft inverts."""
+
+    def __init__(self, n_real: int, radix: int = 2, T=forward_fft, max_batch: int = 1, device: int = 0):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self._lib.sdsp_hip_rfft_plan_create(C.byref(self._h), n_real, radix, T.direction, max_batch, device))
+        self.n_real, self.radix, self.direction, self.device = n_real, radix, T.direction, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdsp_hip_fft_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def exec(self, x):
+        """x: contiguous float32 device tensor (..., n_real), transformed in place; returns the complex
+        view (forward) or x itself (reverse: pass the float32 view of the packed spectrum)."""
+        import torch
+        if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.n_real:
+            raise ValueError("exec needs a contiguous float32 device tensor (..., n_real)")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        L.check(self._lib.sdsp_hip_fft_exec(self._h, x.data_ptr(), x.numel() // self.n_real, stream))
+        if self.direction == L.FORWARD:
+            return torch.view_as_complex(x.view(*x.shape[:-1], self.n_real // 2, 2))
+        return x
+
+
 _plan_cache: dict = {}
 
 

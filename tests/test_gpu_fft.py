@@ -264,6 +264,38 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
         sd.FftPlan(n, radix, sd.reverse_fft, prec).convolve(torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda())
 
 
+@pytest.mark.parametrize("n_real,radix,batch", [(32, 2, 5), (32, 4, 130), (128, 4, 33), (1024, 2, 7), (2048, 4, 5),
+                                                 (8192, 2, 3), (8192, 4, 2), (32768, 2, 2)])
+def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch):
+    """SURVEY 8(f)-3.  Checker: the reference algorithm on the real signal as a complex one (what the
+    reference's own tests do, testFFT.cpp:23-25): bins 0..n_real/2 of oracle.fft(x + 0j)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n_real + batch)
+    x = rng.standard_normal((batch, n_real)).astype(np.float32)
+    full = oracle.fft(x.astype(np.complex128), 2)  # any valid radix gives the same DFT
+    half = n_real // 2
+    want = full[:, :half].copy()
+    want[:, 0] = full[:, 0].real + 1j * full[:, half].real  # packed: (X[0], X[N/2])
+    fwd = sd.RfftPlan(n_real, radix, sd.forward_fft, max_batch=batch)
+    d = torch.from_numpy(x).cuda()
+    spec = fwd.exec(d)
+    torch.cuda.synchronize()
+    got = spec.cpu().numpy()
+    assert got.shape == (batch, half)
+    assert rel_max_err(got, want) < TOL32, rel_max_err(got, want)
+    # inverse: the oracle's packed spectrum back to the real samples, and the GPU round trip
+    inv = sd.RfftPlan(n_real, radix, sd.reverse_fft, max_batch=batch)
+    packed = torch.view_as_real(torch.from_numpy(want.astype(np.complex64)).cuda()).reshape(batch, n_real).contiguous()
+    back = inv.exec(packed)
+    torch.cuda.synchronize()
+    assert rel_max_err(back.cpu().numpy(), x) < TOL32
+    again = inv.exec(torch.view_as_real(spec).reshape(batch, n_real))
+    torch.cuda.synchronize()
+    assert rel_max_err(again.cpu().numpy(), x) < 2e-6
+    with pytest.raises(sd.SdspHipError):
+        sd.RfftPlan(4096, 4)  # n_real/2 = 2048 is not a power of 4
+
+
 def test_plan_twiddles_are_the_rounded_reference_row(sd, torch_cuda, fft_golden):
     # a4: the HBM-resident table equals the reference's last table row rounded once to fp32
     plan = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32)
