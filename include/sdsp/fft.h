@@ -197,6 +197,30 @@ private:
     std::unique_ptr<detail::fft_plan_handle> m_h;
 };
 
+// real-input packing: n_real float samples <-> packed half spectrum (n_real/2 complex,
+// element 0 = (X[0], X[n_real/2])), in place, half the bytes of the complex transform.
+class rfft_plan {
+public:
+    rfft_plan(std::uint32_t n_real, int radix = 2, int direction = SDSP_HIP_FORWARD, std::uint64_t max_batch = 1, int device = 0)
+        : m_n_real(n_real)
+    {
+        detail::check(sdsp_hip_rfft_plan_create(&m_plan, n_real, radix, direction, max_batch, device));
+    }
+    ~rfft_plan() { sdsp_hip_fft_plan_destroy(m_plan); }
+    rfft_plan(const rfft_plan &) = delete;
+    rfft_plan &operator=(const rfft_plan &) = delete;
+    std::uint32_t size() const noexcept { return m_n_real; }
+    void exec(float *device_data, std::uint64_t batch, void *stream = nullptr)
+    {
+        detail::check(sdsp_hip_fft_exec(m_plan, device_data, batch, stream));
+    }
+    void exec_host(float *host_data, std::uint64_t batch) { detail::check(sdsp_hip_fft_exec_host(m_plan, host_data, batch)); }
+
+private:
+    std::uint32_t m_n_real;
+    sdsp_hip_fft_plan *m_plan{ nullptr };
+};
+
 // batch of `batch` transforms of length n in host memory, in place
 template <class T = forward_fft, typename real_t> void fft_batch(int radix, std::complex<real_t> *data, std::uint32_t n, std::uint64_t batch)
 {

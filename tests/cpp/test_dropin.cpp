@@ -440,6 +440,34 @@ void test_next_rows()
     sdsp_hip_free(dx, 0);
     sdsp_hip_free(dh, 0);
 
+    // real-input packing: forward against the f64 drop-in transform of the same real signal, then back
+    {
+        constexpr size_t NR = 1024;
+        std::vector<float> r(NR * 2);
+        for (auto &v : r)
+            v = nd(gen);
+        std::vector<float> keep = r;
+        sdsp::complex_array<NR> full{};
+        for (size_t i = 0; i < NR; i++)
+            full[i] = static_cast<double>(r[NR + i]); // second transform of the batch
+        sdsp::fft_radix2(full);
+        sdsp::rfft_plan fwd(NR, 2, SDSP_HIP_FORWARD, 2), inv(NR, 2, SDSP_HIP_REVERSE, 2);
+        fwd.exec_host(r.data(), 2);
+        double pk = 0, er = 0;
+        for (size_t k = 1; k < NR / 2; k++) {
+            pk = std::max(pk, std::abs(full[k]));
+            er = std::max(er, std::abs(std::complex<double>(r[NR + 2 * k], r[NR + 2 * k + 1]) - full[k]));
+        }
+        er = std::max(er, std::abs(static_cast<double>(r[NR]) - full[0].real()));
+        er = std::max(er, std::abs(static_cast<double>(r[NR + 1]) - full[NR / 2].real()));
+        REQUIRE(er / pk < 1e-6);
+        inv.exec_host(r.data(), 2);
+        double worst = 0;
+        for (size_t i = 0; i < r.size(); i++)
+            worst = std::max(worst, static_cast<double>(std::abs(r[i] - keep[i])));
+        REQUIRE(worst < 1e-5);
+    }
+
     // interleaved bank == channel-major bank on the transposed data, bit for bit (f64)
     constexpr size_t C = 6, S = 200;
     std::vector<double> cm(C * S), il(S * C);
