@@ -142,14 +142,29 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
     const uint32_t live = (uint32_t)have * N;                    // valid points (ragged last workgroup)
     float2 *base = data + first * N;
 
-    // 1. HBM -> LDS, 16 bytes per lane (two points), linear
+    // 1. HBM -> LDS, 16 bytes per lane (two points), linear.  Full workgroups (all but possibly the
+    // last) take the unpredicated path: eight back-to-back loads with immediate offsets.
+    const bool whole = have == (uint64_t)G;
+    if (whole) {
+        float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t e = 2 * (tid + THREADS * k);
-        if (e < live) {
-            const float4 v = gload16<NT>(reinterpret_cast<const float4 *>(base + e));
-            lds[slot(e)] = float2{ v.x, v.y };
-            lds[slot(e + 1)] = float2{ v.z, v.w };
+        for (int k = 0; k < 8; k++)
+            v[k] = gload16<NT>(reinterpret_cast<const float4 *>(base) + tid + THREADS * k);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t e = 2 * (tid + THREADS * k);
+            lds[slot(e)] = float2{ v[k].x, v[k].y };
+            lds[slot(e + 1)] = float2{ v[k].z, v[k].w };
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t e = 2 * (tid + THREADS * k);
+            if (e < live) {
+                const float4 v = gload16<NT>(reinterpret_cast<const float4 *>(base + e));
+                lds[slot(e)] = float2{ v.x, v.y };
+                lds[slot(e + 1)] = float2{ v.z, v.w };
+            }
         }
     }
     __syncthreads();
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const uint32_t e = 2 * (tid + THREADS * k);
-        if (e < live) {
+        if (whole || e < live) {
             const uint32_t tb = e & ~(uint32_t)(N - 1), q = e & (N - 1);
             float2 a = lds[slot(tb + reversed<RADIX, LOG2N>(q))];
             float2 c = lds[slot(tb + reversed<RADIX, LOG2N>(q + 1))];
