@@ -33,6 +33,7 @@ SOURCES = {
     "fft4096.hip": ["-fno-slp-vectorize"],
     "fft1m.hip": ["-fno-slp-vectorize"],  # SLP packing cost 44-76 B/lane of scratch here
     "fft_reg.hip": ["-fno-slp-vectorize"],
+    "fft_reg64.hip": ["-fno-slp-vectorize"],
     "iir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
 }
 

@@ -128,7 +128,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r4_f32(a, p->variant, stream);
     }
 
-    if (p->path == PATH_REG && p->variant == 0 && p->n == 4096 && p->radix == 2 && !p->real_mode) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->n == 4096 && p->radix == 2 &&
+        !p->real_mode) {
         fft4096_args a;
         a.data = data;
         a.tw = p->tw;
@@ -138,7 +139,21 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r2_f32(a, stream);
     }
 
-    if (p->path == PATH_REG && p->variant < 3) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = 1.0f;
+        a.scale_d = 1.0 / p->n;
+        a.reverse = rev;
+        a.nontemporal = 1;
+        return launch_fft_reg_f64(a, stream);
+    }
+
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant < 3) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->tw;
@@ -408,6 +423,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
             p->path = PATH_FFT4096;
         else if (precision == SDSP_HIP_F32 && fft_reg_supports(n, radix))
             p->path = PATH_REG;
+        else if (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))
+            p->path = PATH_REG;
         else
             p->path = PATH_TILE;
         make_twiddles(n, direction, w);
@@ -639,7 +656,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_FFT1M && p->variant < 8)
         name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
     if (p->path == PATH_REG && p->variant < 3)
-        name = p->real_mode ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
+        name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
+               p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

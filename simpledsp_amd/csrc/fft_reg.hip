@@ -27,54 +27,10 @@ namespace
 using passes::cmul;
 using passes::mul_w16;
 using passes::r2_pass;
+using passes::r4_pass;
 using passes::rot90;
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return passes::cadd(a, b); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return passes::csub(a, b); }
-
-// ---- radix-4: stage X pairs k = j + 4q over q (offset 4), stage Y pairs 4q + q' over q' (offset 1).
-// w1[q-1]: thread twiddle of stage X's output q; w2[q'-1]: of stage Y's output q'.  fft.h:342-345.
-template <bool REV> __device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d)
-{
-    const float2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = rot90<REV>(b - d);
-    a = t0 + t2;
-    b = t1 + t3;
-    c = t0 - t2;
-    d = t1 - t3;
-}
-template <bool REV, bool TW, bool BOTH>
-__device__ __forceinline__ void r4_pass(float2 (&x)[16], const float2 (&w1)[3], const float2 (&w2)[3])
-{
-    if constexpr (BOTH) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            bfly4<REV>(x[j], x[j + 4], x[j + 8], x[j + 12]);
-        x[5] = mul_w16<REV, 1>(x[5]);
-        x[6] = mul_w16<REV, 2>(x[6]);
-        x[7] = mul_w16<REV, 3>(x[7]);
-        x[9] = mul_w16<REV, 2>(x[9]);
-        x[10] = mul_w16<REV, 4>(x[10]);
-        x[11] = mul_w16<REV, 6>(x[11]);
-        x[13] = mul_w16<REV, 3>(x[13]);
-        x[14] = mul_w16<REV, 6>(x[14]);
-        x[15] = mul_w16<REV, 9>(x[15]);
-        if constexpr (TW) {
-#pragma unroll
-            for (int q = 1; q < 4; q++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    x[j + 4 * q] = cmul(x[j + 4 * q], w1[q - 1]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bfly4<REV>(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-        if constexpr (TW) {
-            x[4 * q + 1] = cmul(x[4 * q + 1], w2[0]);
-            x[4 * q + 2] = cmul(x[4 * q + 2], w2[1]);
-            x[4 * q + 3] = cmul(x[4 * q + 3], w2[2]);
-        }
-    }
-}
 
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 gload16(const float4 *p)

@@ -75,6 +75,7 @@ struct fft_reg_args {
     int radix;
     uint64_t batch;
     float scale;
+    double scale_d = 1.0;      // f64 kernels
     int reverse;
     int nontemporal;
     int real_mode = 0;         // 0 complex; 1 real forward (split); 2 real inverse (merge): SURVEY 8(f)-3
@@ -82,6 +83,8 @@ struct fft_reg_args {
 };
 bool fft_reg_supports(uint32_t n, int radix);
 int launch_fft_reg_f32(const fft_reg_args &a, void *stream);
+bool fft_reg64_supports(uint32_t n, int radix); // f64 family: 16 .. 8192
+int launch_fft_reg_f64(const fft_reg_args &a, void *stream);
 
 // fast path: batched n = 2^20, radix 2, f32 (BASELINE config 3), one chunk of transforms
 struct fft1m_args {
