@@ -619,6 +619,20 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
         return rc;
     if (p->path == PATH_FFT4096 && p->variant == 0)
         return launch_fft4096_conv_f32(data, p->tw, h, batch, stream);
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = 0;
+        a.nontemporal = 1;
+        a.real_mode = 3; // fused convolution: one kernel, h travels in tw2
+        a.tw2 = h;
+        return launch_fft_reg_f32(a, stream);
+    }
     if (!p->partner) {
         if (int rc = sdsp_hip_fft_plan_create(&p->partner, p->n, p->radix, SDSP_HIP_REVERSE, p->precision,
                                               p->max_batch, p->device))

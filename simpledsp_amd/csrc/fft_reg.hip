@@ -75,6 +75,7 @@ template <int RADIX, int LOG2N> __device__ __forceinline__ uint32_t reversed(uin
 //     passes; the reverse transform then yields z, i.e. the real samples.
 // Half the HBM bytes of pushing a real signal through the complex transform (what every reference
 // test does, testFFT.cpp:23-25,84-90).  tw2 = W_2N^k, direction-folded like tw.
+// MODE 3: fused fast convolution data <- IFFT(FFT(data) .* h), tw2 = h (see below).
 template <int RADIX, int LOG2N, bool REV, bool NT, int MODE>
 __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(float2 *__restrict__ data,
                                                                              const float2 *__restrict__ tw,
@@ -150,8 +151,12 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
     const uint32_t g = tid / T, t = tid % T; // transform within the workgroup, thread within it
     const uint32_t gbase = g * N;
     float2 x[16];
-    auto run_pass = [&](auto pass_tag) {
+    // one register pass; RV = direction of this pass (differs from REV only in MODE 3, whose second
+    // half runs the reverse transform with the conjugates of the forward twiddles)
+    auto run_pass = [&](auto pass_tag, auto rev_tag) {
         constexpr int I = decltype(pass_tag)::value;
+        constexpr bool RV = decltype(rev_tag)::value;
+        constexpr bool CONJ = RV != REV;
         constexpr bool is_last = I == P - 1;
         constexpr int S = is_last ? 1 : (N >> (4 * (I + 1))); // point stride of this pass
         // thread (b, r): positions b*16*S + r + S*k
@@ -162,37 +167,65 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
             x[k] = lds[slot(p0 + S * k)];
         constexpr bool TW = S > 1;          // r == 0 in the stride-1 pass: all thread twiddles are 1
         const uint32_t unit = r << (4 * I); // r * 16^I: W_N^(unit * m) are this thread's twiddles
+        auto twl = [&](uint32_t idx) {
+            float2 w = tw[idx];
+            if constexpr (CONJ)
+                w.y = -w.y;
+            return w;
+        };
         if constexpr (RADIX == 2) {
             float2 w[4];
             if constexpr (TW) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    w[j] = tw[unit << j];
+                    w[j] = twl(unit << j);
             }
-            r2_pass<REV, TW, is_last ? 4 - LAST : 0>::run(x, w);
+            r2_pass<RV, TW, is_last ? 4 - LAST : 0>::run(x, w);
         } else {
             float2 w1[3], w2[3];
             if constexpr (TW) {
 #pragma unroll
                 for (int q = 1; q < 4; q++) {
-                    w1[q - 1] = tw[unit * q];
-                    w2[q - 1] = tw[unit * 4 * q];
+                    w1[q - 1] = twl(unit * q);
+                    w2[q - 1] = twl(unit * 4 * q);
                 }
             }
-            r4_pass<REV, TW, !(is_last && LAST == 2)>(x, w1, w2);
+            r4_pass<RV, TW, !(is_last && LAST == 2)>(x, w1, w2);
         }
 #pragma unroll
         for (int k = 0; k < 16; k++)
             lds[slot(p0 + S * k)] = x[k];
         __syncthreads();
     };
-    run_pass(std::integral_constant<int, 0>{});
-    if constexpr (P > 1)
-        run_pass(std::integral_constant<int, 1>{});
-    if constexpr (P > 2)
-        run_pass(std::integral_constant<int, 2>{});
-    if constexpr (P > 3)
-        run_pass(std::integral_constant<int, 3>{});
+    auto all_passes = [&](auto rev_tag) {
+        run_pass(std::integral_constant<int, 0>{}, rev_tag);
+        if constexpr (P > 1)
+            run_pass(std::integral_constant<int, 1>{}, rev_tag);
+        if constexpr (P > 2)
+            run_pass(std::integral_constant<int, 2>{}, rev_tag);
+        if constexpr (P > 3)
+            run_pass(std::integral_constant<int, 3>{}, rev_tag);
+    };
+    all_passes(std::integral_constant<bool, REV>{});
+
+    if constexpr (MODE == 3) {
+        // fused fast convolution for the whole family: the forward result sits in
+        // reversed order (position p holds Z[reversed(p)]); swap it back to natural order while
+        // multiplying by H (tw2 = h, natural order), then run the reverse transform in place.
+        for (uint32_t idx = tid; idx < (uint32_t)kPoints; idx += THREADS) {
+            const uint32_t tb = idx & ~(uint32_t)(N - 1), pp = idx & (N - 1);
+            const uint32_t qq = reversed<RADIX, LOG2N>(pp);
+            if (pp < qq) {
+                const float2 a = lds[slot(tb + pp)], c = lds[slot(tb + qq)]; // a = Z[qq], c = Z[pp]
+                lds[slot(tb + pp)] = cmul(c, tw2[pp]);
+                lds[slot(tb + qq)] = cmul(a, tw2[qq]);
+            } else if (pp == qq) {
+                lds[slot(tb + pp)] = cmul(lds[slot(tb + pp)], tw2[pp]);
+            }
+        }
+        __syncthreads();
+        all_passes(std::integral_constant<bool, true>{});
+    }
 
     if constexpr (MODE == 1) {
         // split: Z[k] sits at position reversed(k); pairs (k, N-k) are rewritten in place
@@ -226,7 +259,7 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
             const uint32_t tb = e & ~(uint32_t)(N - 1), q = e & (N - 1);
             float2 a = lds[slot(tb + reversed<RADIX, LOG2N>(q))];
             float2 c = lds[slot(tb + reversed<RADIX, LOG2N>(q + 1))];
-            if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            if constexpr (REV || MODE == 3) { // reverse_fft::ScaleValues, fft.h:128-132
                 a.x *= scale;
                 a.y *= scale;
                 c.x *= scale;
@@ -265,6 +298,8 @@ template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t 
         launch_one<RADIX, LOG2N, false, true, 1>(a, grid, s);
     } else if (a.real_mode == 2) { // real inverse
         launch_one<RADIX, LOG2N, true, true, 2>(a, grid, s);
+    } else if (a.real_mode == 3) { // fused convolution: forward plan, tw2 = h
+        launch_one<RADIX, LOG2N, false, true, 3>(a, grid, s);
     } else if (a.nontemporal) {
         if (a.reverse)
             launch_one<RADIX, LOG2N, true, true, 0>(a, grid, s);

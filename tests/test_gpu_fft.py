@@ -236,7 +236,9 @@ def test_fft1m_chunking_and_two_stream_variants_agree(sd, torch_cuda, oracle):
 
 
 @pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
-                                                     (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2)])
+                                                     (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2),
+                                                     (16, 2, "f32", 300), (64, 4, "f32", 70), (1024, 2, "f32", 9),
+                                                     (2048, 2, "f32", 3), (16384, 4, "f32", 2), (8192, 2, "f32", 2)])
 def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
     """x <- IFFT(FFT(x) .* H).  Checker: the reference's own composition
     fft_radix<forward>(x); x *= H; fft_radix<reverse_fft>(x) through the oracle, in double."""
@@ -251,8 +253,9 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
     plan = sd.FftPlan(n, radix, sd.forward_fft, prec, max_batch=batch)
     tol = 2e-6 if prec == sd.F32 else 8 * n * EPS64  # two transforms and a product
     outs = []
-    for variant in ((0, 1) if (n, radix, prec) == (4096, 4, sd.F32) else (0,)):
-        plan.set_variant(variant)  # 4096/r4/f32: 0 = fused single kernel, 1 = three launches
+    fused = prec == sd.F32 and n <= 16384
+    for variant in ((0, 1) if fused else (0,)):
+        plan.set_variant(variant)  # f32, n <= 16384: 0 = fused single kernel, 1 = three launches
         d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
         plan.convolve(d, hd)
         torch.cuda.synchronize()
