@@ -118,6 +118,15 @@ public:
         store_design(a, b, g, filter_type::band_pass);
     }
 
+    // band-stop: the reference's README TODO (README.md:15); same parameters as set_bp_coeff
+    void set_bs_coeff(double f0, double fs, double q, double gain_in = 1.0)
+    {
+        std::array<double, 3 * m_t> a{}, b{};
+        double g = 0;
+        detail::check(sdsp_hip_iir_design_bs(m_t, f0, fs, q, gain_in, a.data(), b.data(), &g));
+        store_design(a, b, g, filter_type::band_stop);
+    }
+
     void set_hp_coeff(double f0, double fs, double gain_in = 1.0)
     {
         std::array<double, 3 * m_t> a{}, b{};
@@ -225,6 +234,35 @@ public:
     }
 };
 
+// band-stop in the style of the classes above (not in the reference, README.md:15 TODO).  Its numerator
+// [1, -2cos(w0), 1] has a per-design middle term, so it keeps b and runs the generic recurrence.
+template <size_t m_t> class casc_2o_iir_bs : casc_2o_iir_base<m_t> {
+    detail::coeff3_array<m_t> m_b_coeff{};
+
+public:
+    casc_2o_iir_bs() { static_assert(m_t % 2 == 0, "M must be even!"); }
+    void copy_coeff_from(const casc_2o_iir_bs<m_t> &other_filter)
+    {
+        this->copy_design(other_filter);
+        m_b_coeff = other_filter.m_b_coeff;
+    }
+    template <typename iter_t> void process(iter_t begin, iter_t end)
+    {
+        detail::process_single<m_t>(SDSP_HIP_IIR_GENERIC, this->m_gain, this->m_a_coeff, &m_b_coeff, this->m_mem, this->m_pos,
+                                    begin, end);
+    }
+    void set_bs_coeff(double f0, double fs, double q, double gain_in = 1.0)
+    {
+        std::array<double, 3 * m_t> a{}, b{};
+        double g = 0;
+        detail::check(sdsp_hip_iir_design_bs(m_t, f0, fs, q, gain_in, a.data(), b.data(), &g));
+        this->store_design(a, g);
+        for (size_t j = 0; j < m_t; ++j)
+            for (size_t i = 0; i < 3; ++i)
+                m_b_coeff[j][i] = b[3 * j + i];
+    }
+};
+
 // ---- the batched entry: a bank of channels on the device ----------------------------------------
 // `channels` independent streams share one design; per-channel state stays resident in HBM between
 // process() calls.  Data is channel-major: channel c's samples are data[c*stride .. c*stride+samples).
@@ -259,6 +297,12 @@ public:
     {
         detail::check(sdsp_hip_iir_design_bp(m_t, f0, fs, q, gain_in, m_a.data(), m_b.data(), &m_gain));
         redesign(filter_type::band_pass);
+    }
+    // band-stop needs the generic recurrence: construct the bank with kind SDSP_HIP_IIR_GENERIC (the default)
+    void set_bs_coeff(double f0, double fs, double q, double gain_in = 1.0)
+    {
+        detail::check(sdsp_hip_iir_design_bs(m_t, f0, fs, q, gain_in, m_a.data(), m_b.data(), &m_gain));
+        redesign(filter_type::band_stop);
     }
     template <typename other_real_t> void copy_coeff_from(const casc_2o_iir_bank<m_t, other_real_t> &o)
     {

@@ -11,7 +11,8 @@ enum class filter_type : int {
     none = 0,      // freshly constructed filter, no design yet
     low_pass = 1,  // set_lp_coeff: numerator [1, 2, 1]
     high_pass = 2, // set_hp_coeff: numerator [1, -2, 1]
-    band_pass = 3  // set_bp_coeff: numerator [1, 0, -1]
+    band_pass = 3, // set_bp_coeff: numerator [1, 0, -1]
+    band_stop = 4  // set_bs_coeff: numerator [1, -2cos(w0), 1] (the reference's README TODO; not in its enum)
 };
 } // namespace sdsp
 

@@ -46,7 +46,8 @@ typedef enum {
     SDSP_HIP_FILTER_NONE = 0,
     SDSP_HIP_FILTER_LOW_PASS = 1,
     SDSP_HIP_FILTER_HIGH_PASS = 2,
-    SDSP_HIP_FILTER_BAND_PASS = 3
+    SDSP_HIP_FILTER_BAND_PASS = 3,
+    SDSP_HIP_FILTER_BAND_STOP = 4 /* not in the reference (README.md:15 TODO); SURVEY 8(f)-4 */
 } sdsp_hip_filter_type;
 /* which process() body runs: casc_2o_iir::process (casc_2o_iir.h:36-80) or the
  * numerator-folded casc_2o_iir_{lp,hp,bp}::process_spec (:286-295, :344-353, :402-411) */
@@ -168,6 +169,14 @@ int sdsp_hip_iir_design_lp(uint32_t sections, double f0, double fs, double gain_
 int sdsp_hip_iir_design_hp(uint32_t sections, double f0, double fs, double gain_in, double *a,
                            double *b, double *gain);
 int sdsp_hip_iir_design_bp(uint32_t sections, double f0, double fs, double q, double gain_in,
+                           double *a, double *b, double *gain);
+/*
+ * Band-stop design -- the reference's README.md:15 TODO, SURVEY 8(f)-4 (no reference code: parity is
+ * pinned to scipy.signal.butter(btype='bandstop') instead).  Same parameters as design_bp: centre f0,
+ * -3 dB width f0/q, Butterworth prototype of order `sections`.  Every section's numerator is
+ * [1, -2cos(2 pi f0/fs), 1]; run it on a GENERIC plan.
+ */
+int sdsp_hip_iir_design_bs(uint32_t sections, double f0, double fs, double q, double gain_in,
                            double *a, double *b, double *gain);
 /* preload_filter, casc_2o_iir.h:197-214: mem[(sections+1)*3] for a steady input `value` */
 int sdsp_hip_iir_preload(uint32_t sections, int filter_type, const double *a, const double *b,

@@ -73,6 +73,7 @@ class Oracle:
         lib.sdsp_oracle_iir_set_lp_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double]
         lib.sdsp_oracle_iir_set_hp_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double]
         lib.sdsp_oracle_iir_set_bp_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double, C.c_double]
+        lib.sdsp_oracle_iir_set_bs_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double, C.c_double]
         lib.sdsp_oracle_iir_preload_filter.argtypes = [S, C.c_double]
         lib.sdsp_oracle_iir_process.argtypes = [S, C.c_int, C.c_void_p, C.c_size_t]
         self._plans: dict = {}
@@ -163,6 +164,10 @@ class OracleIir:
     def set_bp_coeff(self, f0, fs, q, gain_in=1.0):
         self._o.lib.sdsp_oracle_iir_set_bp_coeff(C.byref(self._s), f0, fs, q, gain_in)
 
+    def set_bs_coeff(self, f0, fs, q, gain_in=1.0):
+        # not in the reference (README TODO); pinned to scipy in tests/test_oracle_iir.py
+        self._o.lib.sdsp_oracle_iir_set_bs_coeff(C.byref(self._s), f0, fs, q, gain_in)
+
     def preload_filter(self, value):
         self._o.lib.sdsp_oracle_iir_preload_filter(C.byref(self._s), value)
 
@@ -172,6 +177,17 @@ class OracleIir:
         if rc:
             raise ValueError(f"iir_process -> {rc}")
         return a
+
+    def set_design(self, a, b, gain, f_type=0):
+        """load given coefficients (the recurrence of casc_2o_iir.h:36-80 does not care where they came from)"""
+        a = np.asarray(a, dtype=np.float64).reshape(-1)
+        b = np.asarray(b, dtype=np.float64).reshape(-1)
+        assert a.size == b.size == 3 * self.m
+        for i in range(3 * self.m):
+            self._s.a[i] = a[i]
+            self._s.b[i] = b[i]
+        self._s.gain = float(gain)
+        self._s.f_type = int(f_type)
 
     def process_inplace(self, a: np.ndarray, kind: int = 0) -> None:
         assert a.dtype == np.float64 and a.flags.c_contiguous

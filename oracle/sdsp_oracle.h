@@ -61,6 +61,8 @@ void sdsp_oracle_iir_copy_coeff_from(sdsp_oracle_iir *f, const sdsp_oracle_iir *
 int sdsp_oracle_iir_set_lp_coeff(sdsp_oracle_iir *f, double f0, double fs, double gain_in);
 int sdsp_oracle_iir_set_hp_coeff(sdsp_oracle_iir *f, double f0, double fs, double gain_in);
 int sdsp_oracle_iir_set_bp_coeff(sdsp_oracle_iir *f, double f0, double fs, double q, double gain_in);
+/* band-stop: README.md:15 TODO, no reference code -- pinned to scipy, see the .c file */
+int sdsp_oracle_iir_set_bs_coeff(sdsp_oracle_iir *f, double f0, double fs, double q, double gain_in);
 void sdsp_oracle_iir_preload_filter(sdsp_oracle_iir *f, double value);
 /* kind 0: casc_2o_iir::process (reads b); 1/2/3: casc_2o_iir_{lp,hp,bp}::process (b folded) */
 int sdsp_oracle_iir_process(sdsp_oracle_iir *f, int kind, double *data, size_t n);

@@ -5,7 +5,7 @@ this package is its Python host mirror.  Importing does not touch the GPU; any c
 the library or without a HIP device raises (there is no CPU path here).
 """
 from ._lib import (F32, F64, FORWARD, REVERSE, IIR_GENERIC, IIR_LP, IIR_HP, IIR_BP, FILTER_NONE,
-                   FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS, SdspHipError, load)
+                   FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS, FILTER_BAND_STOP, SdspHipError, load)
 from .fft import (FftPlan, RfftPlan, fft_radix2, fft_radix4, forward_fft, reverse_fft, log2, log4, isPowerOf2,
                   isPowerOf4, digit_reverse, calc_swap_lookup, calc_twiddles, calc_wCoeffs)
 from .iir import casc_2o_iir, casc_2o_iir_lp, casc_2o_iir_hp, casc_2o_iir_bp
@@ -13,3 +13,4 @@ from .iir import casc_2o_iir, casc_2o_iir_lp, casc_2o_iir_hp, casc_2o_iir_bp
 
 class filter_type:  # filter_type.h:6
     none, low_pass, high_pass, band_pass = 0, 1, 2, 3
+    band_stop = 4  # not in the reference's enum (README.md:15 TODO)

@@ -14,6 +14,7 @@ LIB_PATH = PKG / "lib" / "libsdsp_hip.so"
 F32, F64 = 0, 1
 FORWARD, REVERSE = 1, -1
 FILTER_NONE, FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS = 0, 1, 2, 3
+FILTER_BAND_STOP = 4
 IIR_GENERIC, IIR_LP, IIR_HP, IIR_BP = 0, 1, 2, 3
 MAX_SECTIONS = 16
 
@@ -66,6 +67,7 @@ SIGNATURES = {
     "sdsp_hip_iir_design_lp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_hp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_bp": (_i, [_u32, _d, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
+    "sdsp_hip_iir_design_bs": (_i, [_u32, _d, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_preload": (_i, [_u32, _i, _vp, _vp, _d, _d, _vp]),
     "sdsp_hip_iir_plan_create": (_i, [_pp, _u32, _i, _vp, _vp, _d, _i, _i]),
     "sdsp_hip_iir_plan_destroy": (_i, [_vp]),

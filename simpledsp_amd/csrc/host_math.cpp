@@ -4,6 +4,7 @@
 #include "sdsp_hip_internal.h"
 
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <vector>
 
@@ -142,19 +143,60 @@ int design_bp(uint32_t m, double f0, double fs, double q, double gain_in, double
     return SDSP_HIP_OK;
 }
 
-// preload_filter: casc_2o_iir.h:197-214.  DC propagates section to section only for low_pass.
+// Band-stop design -- the reference's README lists it as TODO (README.md:15); no reference code exists,
+// so this is a new design in the same parameterisation as set_bp_coeff (centre f0, quality q ->
+// -3 dB width f0/q, Butterworth prototype of order m): the band-stop frequency transformation
+// s = tan(e0/2q) (z^2 - 1) / (z^2 - 2 cos(e0) z + 1) applied to each prototype pole p gives the
+// quadratic (p - B) z^2 - 2 p c z + (p + B) = 0; its two roots (and their conjugates, from p*) are
+// the poles of two sections.  Every section has the zero pair e^{+-j e0} (numerator [1, -2c, 1]);
+// the gain normalises each section to 1 at DC.  Checked against scipy.signal.butter(btype='bandstop').
+int design_bs(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b,
+              double *gain)
+{
+    if (m == 0 || m % 2 != 0 || m > SDSP_HIP_MAX_SECTIONS)
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "M must be even! (and <= SDSP_HIP_MAX_SECTIONS)");
+    if (!a || !b || !gain)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null output pointer");
+    using cplx = std::complex<double>;
+    double g = gain_in;
+    const double e0 = 2 * M_PI * f0 / fs;
+    const double c = std::cos(e0);
+    const double bw = std::tan(e0 / (2 * q));
+    for (uint32_t k = 0; k < m / 2; k++) {
+        const double th = (2 * k + 1) * M_PI / (2.0 * m);
+        const cplx p(-std::sin(th), std::cos(th));
+        const cplx qa = p - bw, qb = -2.0 * p * c, qc = p + bw;
+        const cplx disc = std::sqrt(qb * qb - 4.0 * qa * qc);
+        const cplx z[2] = { (-qb + disc) / (2.0 * qa), (-qb - disc) / (2.0 * qa) };
+        for (int h = 0; h < 2; h++) {
+            const uint32_t s = 2 * k + h;
+            a[3 * s + 0] = 1.0;
+            a[3 * s + 1] = -2 * z[h].real();
+            a[3 * s + 2] = std::norm(z[h]);
+            b[3 * s + 0] = 1.0;
+            b[3 * s + 1] = -2 * c;
+            b[3 * s + 2] = 1.0;
+            g *= (1 + a[3 * s + 1] + a[3 * s + 2]) / (2 - 2 * c);
+        }
+    }
+    *gain = g;
+    return SDSP_HIP_OK;
+}
+
+// preload_filter: casc_2o_iir.h:197-214.  DC propagates section to section only for low_pass
+// (and band_stop, which also passes DC; not in the reference).
 int preload(uint32_t m, int filter_type, const double *a, const double *b, double gain,
             double value, double *mem)
 {
     if (m == 0 || m % 2 != 0 || m > SDSP_HIP_MAX_SECTIONS)
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "M must be even! (and <= SDSP_HIP_MAX_SECTIONS)");
-    if (!mem || (filter_type == SDSP_HIP_FILTER_LOW_PASS && (!a || !b)))
+    if (!mem || ((filter_type == SDSP_HIP_FILTER_LOW_PASS || filter_type == SDSP_HIP_FILTER_BAND_STOP) && (!a || !b)))
         return fail(SDSP_HIP_ERR_INVALID_ARG, "null pointer");
     double v = value * gain;
     std::memset(mem, 0, sizeof(double) * 3 * (m + 1));
     for (int i = 0; i < 3; i++)
         mem[i] = v;
-    if (filter_type == SDSP_HIP_FILTER_LOW_PASS) {
+    if (filter_type == SDSP_HIP_FILTER_LOW_PASS || filter_type == SDSP_HIP_FILTER_BAND_STOP) {
         for (uint32_t j = 1; j < m + 1; j++) {
             v /= 1 + a[3 * (j - 1) + 1] + a[3 * (j - 1) + 2];
             v *= b[3 * (j - 1) + 0] + b[3 * (j - 1) + 1] + b[3 * (j - 1) + 2];
@@ -232,6 +274,10 @@ int sdsp_hip_iir_design_hp(uint32_t m, double f0, double fs, double gain_in, dou
 int sdsp_hip_iir_design_bp(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain)
 {
     return design_bp(m, f0, fs, q, gain_in, a, b, gain);
+}
+int sdsp_hip_iir_design_bs(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain)
+{
+    return design_bs(m, f0, fs, q, gain_in, a, b, gain);
 }
 int sdsp_hip_iir_preload(uint32_t m, int filter_type, const double *a, const double *b, double gain, double value, double *mem)
 {

@@ -57,6 +57,13 @@ class casc_2o_iir:
         self.m_gain = g.value
         self._designed(L.FILTER_BAND_PASS)
 
+    def set_bs_coeff(self, f0, fs, q, gain_in=1.0):  # README.md:15 TODO in the reference; generic kind only
+        g = C.c_double()
+        L.check(self._lib.sdsp_hip_iir_design_bs(self.m_t, f0, fs, q, gain_in, self.m_a_coeff.ctypes.data,
+                                                 self.m_b_coeff.ctypes.data, C.byref(g)))
+        self.m_gain = g.value
+        self._designed(L.FILTER_BAND_STOP)
+
     def copy_coeff_from(self, other: "casc_2o_iir"):  # casc_2o_iir.h:28-34: design, not state
         self.m_gain = other.m_gain
         self.m_a_coeff = other.m_a_coeff.copy()

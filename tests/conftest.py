@@ -55,8 +55,29 @@ def design(f, ftype, f0, fs, q, gain_in=1.0):
         f.set_hp_coeff(f0, fs, gain_in)
     elif ftype == 3:
         f.set_bp_coeff(f0, fs, q, gain_in)
+    elif ftype == 4:  # band-stop: not in the reference (README TODO), see test_band_stop_*
+        f.set_bs_coeff(f0, fs, q, gain_in)
     else:
         raise RuntimeError("Unknown filter type")
+
+
+def band_edges(f0, fs, q):
+    """-3 dB edges (Hz) of the set_bp_coeff / set_bs_coeff parameterisation: width f0/q, centre
+    angle e0 with cos(e0) = cos((e1+e2)/2) / cos((e2-e1)/2) -- the relation the reference's
+    test_data/findIIRCutoffFreq.m solves numerically for its Octave band-pass fixtures."""
+    e0 = 2 * np.pi * f0 / fs
+    d = e0 / q
+    mid = np.arccos(np.cos(e0) * np.cos(d / 2))
+    return (mid - d / 2) * fs / (2 * np.pi), (mid + d / 2) * fs / (2 * np.pi)
+
+
+def scipy_band_stop_sos(m, f0, fs, q):
+    """Third opinion for the band-stop design: Butterworth order m between band_edges."""
+    import scipy.signal
+    return scipy.signal.butter(m, band_edges(f0, fs, q), "bandstop", fs=fs, output="sos")
+
+
+BAND_STOP_CASES = [(200.0, 39e3, 1.4), (2000.0, 39e3, 0.8), (15000.0, 39e3, 2.0), (10e3, 100e3, 1.1)]
 
 
 def rel_max_err(got, ref):

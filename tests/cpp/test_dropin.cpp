@@ -403,6 +403,38 @@ void test_batched_entries()
 }
 
 // the 8(f) additions through the C++ surface: fused convolution and the interleaved bank layout
+// band-stop (the reference's README.md:15 TODO): generic == folded class bit for bit; a tone at f0 is
+// removed, DC passes; preload_filter gives the steady state from the first sample
+void test_band_stop()
+{
+    constexpr double fs{ 100e3 }, f0{ 10e3 }, Q{ 1.1 };
+    sdsp::casc_2o_iir<4> g;
+    g.set_bs_coeff(f0, fs, Q);
+    REQUIRE(g.type() == sdsp::filter_type::band_stop);
+    sdsp::casc_2o_iir_bs<4> s;
+    s.set_bs_coeff(f0, fs, Q);
+    std::array<double, 4096> a{}, b{};
+    for (size_t i = 0; i < a.size(); i++)
+        a[i] = b[i] = 3.0 + std::sin(2 * M_PI * f0 / fs * static_cast<double>(i));
+    g.process(a.begin(), a.end());
+    s.process(b.begin(), b.end());
+    REQUIRE(a == b);
+    double worst = 0;
+    for (size_t i = 2048; i < a.size(); i++)
+        worst = std::max(worst, std::abs(a[i] - 3.0));
+    REQUIRE(worst < 1e-9);
+    std::array<double, 256> steady;
+    steady.fill(10.0);
+    sdsp::casc_2o_iir<4> p;
+    p.set_bs_coeff(f0, fs, Q);
+    p.preload_filter(10.0);
+    p.process(steady.begin(), steady.end());
+    worst = 0;
+    for (double v : steady)
+        worst = std::max(worst, std::abs(v - 10.0));
+    REQUIRE(worst < 1e-9);
+}
+
 void test_next_rows()
 {
     std::mt19937_64 gen(7);
@@ -509,6 +541,7 @@ int main(int argc, char **argv)
         test_iir_benchmark_bodies();
         test_batched_entries();
         test_next_rows();
+        test_band_stop();
     } catch (const sdsp::hip_error &e) {
         std::printf("GPU path unavailable (no CPU fallback): %s (code %d)\n", e.what(), e.code());
         return 3;

@@ -68,6 +68,39 @@ def test_coefficient_design_matches_oracle(oracle, m):
         assert f.m_gain == fo.gain and f.m_f_type == fo.f_type
 
 
+@pytest.mark.parametrize("m", [2, 4, 8])
+def test_band_stop_design_matches_oracle_and_scipy(oracle, m):
+    """sdsp_hip_iir_design_bs (README.md:15 TODO, no reference code): the C++ product version against the
+    independent C99 oracle version (rounding-level agreement: different complex-arithmetic libraries) and
+    against scipy's Butterworth band-stop on the impulse response."""
+    import scipy.signal
+    from conftest import BAND_STOP_CASES, scipy_band_stop_sos
+    for f0, fs, q in BAND_STOP_CASES:
+        f = sd.casc_2o_iir(m)
+        f.set_bs_coeff(f0, fs, q, 1.7)
+        fo = oracle.iir(m)
+        fo.set_bs_coeff(f0, fs, q, 1.7)
+        assert f.m_f_type == fo.f_type == 4
+        assert np.array_equal(f.m_b_coeff, fo.b)
+        assert np.abs(f.m_a_coeff - fo.a).max() < 1e-14 and abs(f.m_gain / fo.gain - 1) < 1e-11
+        sos = np.hstack([f.m_b_coeff, f.m_a_coeff])
+        sos[0, :3] *= f.m_gain / 1.7
+        x = np.zeros(1000)
+        x[0] = 1.0
+        assert np.abs(scipy.signal.sosfilt(sos, x) - scipy.signal.sosfilt(scipy_band_stop_sos(m, f0, fs, q), x)).max() < 1e-12
+    # preload of a band-stop propagates DC through the sections like low_pass
+    lib = sd.load()
+    f = sd.casc_2o_iir(4)
+    f.set_bs_coeff(10e3, 100e3, 1.1)
+    mem = np.zeros((5, 3))
+    L.check(lib.sdsp_hip_iir_preload(4, f.m_f_type, f.m_a_coeff.ctypes.data, f.m_b_coeff.ctypes.data, f.m_gain, 10.0,
+                                     mem.ctypes.data))
+    fo = oracle.iir(4)
+    fo.set_bs_coeff(10e3, 100e3, 1.1)
+    fo.preload_filter(10.0)
+    assert np.abs(mem - fo.mem).max() < 1e-10 and abs(mem[4, 0] - 10.0) < 1e-9
+
+
 def test_design_matches_reference_fixtures(iir_golden):
     for tag in iir_golden["csv_names"]:
         ftype, fs, f0, q = iir_golden[f"{tag}__params"]

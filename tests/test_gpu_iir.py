@@ -9,7 +9,7 @@ bit-identical to one long call (testIIR.cpp:61-75).
 import numpy as np
 import pytest
 
-from conftest import design, impulse_csvs, read_impulse_csv, rel_max_err
+from conftest import BAND_STOP_CASES, design, impulse_csvs, read_impulse_csv, rel_max_err, scipy_band_stop_sos
 
 pytestmark = pytest.mark.gpu
 
@@ -186,6 +186,43 @@ def test_interleaved_layout_is_bit_identical_to_channel_major(sd, torch_cuda, pr
                     torch.cuda.synchronize()
                     assert torch.equal(y.t(), want), (channels, samples, nm, kind, variant)
                     assert torch.equal(bank.state, ref.state)
+
+
+@pytest.mark.parametrize("m", [2, 4, 8])
+def test_band_stop_f64_and_f32(sd, torch_cuda, oracle, m):
+    """SURVEY 8(f)-4 / README.md:15 TODO.  No reference code exists: the design is pinned to scipy's
+    Butterworth band-stop at the reference's 1e-12 (testIIR.cpp:59); the recurrence itself is the reference's
+    generic one, so the f64 kernel is bit-exact against the oracle run with the same coefficients."""
+    import scipy.signal
+    rng = np.random.default_rng(m)
+    for f0, fs, q in BAND_STOP_CASES:
+        bank = _bank(sd, m, 3, sd.F64, sd.IIR_GENERIC, 4, f0, fs, q)
+        x = np.zeros((3, 1000))
+        x[0, 0] = 1.0
+        x[1:] = rng.standard_normal((2, 1000))
+        out = _process(torch_cuda, bank, x)
+        sos = scipy_band_stop_sos(m, f0, fs, q)
+        assert np.abs(out[0] - scipy.signal.sosfilt(sos, x[0])).max() < 1e-12
+        assert rel_max_err(out[1], scipy.signal.sosfilt(sos, x[1])) < 1e-10
+        fo = oracle.iir(m)
+        fo.set_design(bank.m_a_coeff, bank.m_b_coeff, bank.m_gain, 4)
+        assert np.array_equal(out[2], fo.process(x[2], 0))
+    # streaming, preload (DC passes a band-stop), f32 at the normwise 1e-6
+    f0, fs, q = 10e3, 100e3, 1.1
+    x = rng.standard_normal((70, 1024))
+    whole = _process(torch_cuda, _bank(sd, m, 70, sd.F64, sd.IIR_GENERIC, 4, f0, fs, q), x)
+    bank = _bank(sd, m, 70, sd.F64, sd.IIR_GENERIC, 4, f0, fs, q)
+    parts = np.concatenate([_process(torch_cuda, bank, x[:, i:i + 64]) for i in range(0, 1024, 64)], axis=1)
+    assert np.array_equal(whole, parts)
+    bank = _bank(sd, m, 5, sd.F64, sd.IIR_GENERIC, 4, f0, fs, q)
+    bank.preload_filter(10.0)
+    assert np.abs(_process(torch_cuda, bank, np.full((5, 256), 10.0)) - 10.0).max() < 1e-9
+    bank32 = _bank(sd, m, 70, sd.F32, sd.IIR_GENERIC, 4, f0, fs, q)
+    x32 = x.astype(np.float32)
+    got = _process(torch_cuda, bank32, x32)
+    fo = oracle.iir(m)
+    fo.set_design(bank32.m_a_coeff, bank32.m_b_coeff, bank32.m_gain, 4)
+    assert rel_max_err(got[7], fo.process(x32[7].astype(np.float64), 0)) < 1e-6
 
 
 def test_host_pointer_entry_point(sd, torch_cuda, iir_golden):

@@ -7,7 +7,7 @@ reference's own tests restated from test/testIIR.cpp: Octave CSV impulse respons
 import numpy as np
 import pytest
 
-from conftest import design, impulse_csvs, read_impulse_csv
+from conftest import BAND_STOP_CASES, band_edges, design, impulse_csvs, read_impulse_csv, scipy_band_stop_sos
 
 KINDS = {"lp": 1, "hp": 2, "bp": 3}
 
@@ -106,3 +106,64 @@ def test_copy_coeff_from_copies_design_not_state(oracle):
     b.copy_coeff_from(a)
     assert np.array_equal(a.a, b.a) and np.array_equal(a.b, b.b) and a.gain == b.gain
     assert b.pos == 0 and not b.mem.any() and a.mem.any()
+
+
+# ---- band-stop: the reference's README TODO (README.md:15).  There is no reference code, so parity with
+# the reference is UNPINNED; the design is pinned to scipy (SURVEY 8c "independent third opinions").
+
+def test_band_edge_relation_reproduces_the_octave_band_pass_fixtures(oracle):
+    """band_edges() is the closed form of test_data/findIIRCutoffFreq.m: scipy's band-PASS between those
+    edges must reproduce the reference's Octave band-pass CSVs -- that pins the (f0, q) -> edges map the
+    band-stop check below relies on."""
+    import scipy.signal
+    for csv in impulse_csvs():
+        ftype, fs, f0, q, expected = read_impulse_csv(csv)
+        if ftype != 3:
+            continue
+        sos = scipy.signal.butter(4, band_edges(f0, fs, q), "bandpass", fs=fs, output="sos")
+        x = np.zeros(expected.size)
+        x[0] = 1.0
+        assert np.abs(scipy.signal.sosfilt(sos, x) - expected).max() < 1e-9, csv.stem
+
+
+@pytest.mark.parametrize("m", [2, 4, 6, 8])
+@pytest.mark.parametrize("f0,fs,q", BAND_STOP_CASES)
+def test_band_stop_design_against_scipy(oracle, m, f0, fs, q):
+    import scipy.signal
+    f = oracle.iir(m)
+    f.set_bs_coeff(f0, fs, q)
+    assert f.f_type == 4
+    x = np.zeros(1000)
+    x[0] = 1.0
+    got = f.process(x, 0)
+    ref = scipy.signal.sosfilt(scipy_band_stop_sos(m, f0, fs, q), x)
+    assert np.abs(got - ref).max() < 1e-12  # testIIR.cpp:59's bound
+    # structure: unit leading taps, zero pair exactly on the centre frequency, unit gain at DC
+    c = np.cos(2 * np.pi * f0 / fs)
+    assert np.array_equal(f.b, np.tile([1.0, -2 * c, 1.0], (m, 1))) and np.all(f.a[:, 0] == 1.0)
+    dc = f.gain * np.prod(f.b.sum(axis=1) / f.a.sum(axis=1))
+    assert abs(dc - 1.0) < 1e-12
+    w0 = np.exp(1j * 2 * np.pi * f0 / fs)
+    h0 = f.gain * np.prod(np.polyval(f.b.T, w0) / np.polyval(f.a.T, w0))
+    assert abs(h0) < 1e-10  # the notch
+
+
+def test_band_stop_blocks_gain_and_preload(oracle):
+    f0, fs, q = 10e3, 100e3, 1.1
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(1024)
+    whole = oracle.iir(4)
+    whole.set_bs_coeff(f0, fs, q)
+    y = whole.process(x, 0)
+    blocks = oracle.iir(4)
+    blocks.set_bs_coeff(f0, fs, q)
+    yb = np.concatenate([blocks.process(x[i:i + 32], 0) for i in range(0, 1024, 32)])
+    assert np.array_equal(y, yb)  # testIIR.cpp:61-75 semantics
+    g = oracle.iir(4)
+    g.set_bs_coeff(f0, fs, q, 2.0)
+    assert np.abs(g.process(x, 0) - 2.0 * y).max() < 1e-12
+    p = oracle.iir(4)
+    p.set_bs_coeff(f0, fs, q)
+    p.preload_filter(10.0)  # DC passes a band-stop: steady state from the first sample (:173-195 style)
+    steady = p.process(np.full(256, 10.0), 0)
+    assert np.abs(steady - 10.0).max() < 1e-9
