@@ -59,6 +59,7 @@ typedef enum {
 } sdsp_hip_iir_kind;
 
 #define SDSP_HIP_MAX_SECTIONS 16
+#define SDSP_HIP_FIR_MAX_TAPS 4096
 
 typedef struct sdsp_hip_fft_plan sdsp_hip_fft_plan;
 typedef struct sdsp_hip_iir_plan sdsp_hip_iir_plan;
@@ -224,6 +225,42 @@ int sdsp_hip_iir_process_sharded(sdsp_hip_iir_plan *const *plans, int n_plans, v
 /* bytes of a state buffer for `channels` channels */
 int sdsp_hip_iir_state_bytes(const sdsp_hip_iir_plan *plan, uint64_t channels, uint64_t *bytes);
 int sdsp_hip_iir_plan_set_variant(sdsp_hip_iir_plan *plan, int variant);
+
+/* ------------------------------------------------------------------ FIR filter bank */
+
+/*
+ * The reference lists "FIR filter" as a TODO (README.md:16) and has no code for it -- SURVEY 8(f)-4.
+ * These entries follow the conventions of the IIR bank above (what sdsp::casc_2o_iir does for one
+ * stream, casc_2o_iir.h:36-80: in place, stateful across calls); parity is pinned to
+ * scipy.signal.firwin / lfilter, not to the reference.
+ *
+ * Design: Hamming-windowed sinc, `taps` coefficients h[0..taps), unit gain (times gain_in) in the
+ * pass band.  filter_type: LOW_PASS / HIGH_PASS (cutoff f0; q ignored), BAND_PASS / BAND_STOP (centre
+ * f0, edges f0 -+ f0/(2q)).  Filters that pass fs/2 (HIGH_PASS, BAND_STOP) need an odd tap count.
+ */
+int sdsp_hip_fir_design(uint32_t taps, int filter_type, double f0, double fs, double q,
+                        double gain_in, double *h);
+
+typedef struct sdsp_hip_fir_plan sdsp_hip_fir_plan;
+/* h: taps doubles (host), rounded to the plan precision and kept resident on the device */
+int sdsp_hip_fir_plan_create(sdsp_hip_fir_plan **plan, uint32_t taps, const double *h,
+                             int precision, int device);
+int sdsp_hip_fir_plan_destroy(sdsp_hip_fir_plan *plan);
+/*
+ * y[n] = sum_{k<taps} h[k] x[n-k] for `channels` independent streams, in place.  data: DEVICE pointer,
+ * channel-major like sdsp_hip_iir_process (channel c = data[c*stride .. +samples)).
+ * state: DEVICE pointer or NULL (zero history, final history dropped); otherwise
+ * state[c*(taps-1) + j] = x_c[n-1-j] (j = 0 is the newest input), plan precision, read at entry and
+ * written at exit so block-by-block calls equal one long call bit for bit.  Accumulation order:
+ * ascending k, one multiply and one add per tap in f64 (bit-identical to the CPU oracle), FMA in f32.
+ */
+int sdsp_hip_fir_process(sdsp_hip_fir_plan *plan, void *data, uint64_t channels, uint64_t samples,
+                         uint64_t stride, void *state, void *stream);
+/* same with HOST pointers (synchronous) */
+int sdsp_hip_fir_process_host(sdsp_hip_fir_plan *plan, void *host_data, uint64_t channels,
+                              uint64_t samples, uint64_t stride, void *host_state);
+int sdsp_hip_fir_state_bytes(const sdsp_hip_fir_plan *plan, uint64_t channels, uint64_t *bytes);
+int sdsp_hip_fir_plan_set_variant(sdsp_hip_fir_plan *plan, int variant);
 
 #ifdef __cplusplus
 }

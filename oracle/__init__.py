@@ -75,6 +75,9 @@ class Oracle:
         lib.sdsp_oracle_iir_set_bp_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double, C.c_double]
         lib.sdsp_oracle_iir_set_bs_coeff.argtypes = [S, C.c_double, C.c_double, C.c_double, C.c_double]
         lib.sdsp_oracle_iir_preload_filter.argtypes = [S, C.c_double]
+        lib.sdsp_oracle_fir_design.argtypes = [C.c_uint, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib.sdsp_oracle_fir_process.argtypes = [C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.sdsp_oracle_fir_process.restype = None
         lib.sdsp_oracle_iir_process.argtypes = [S, C.c_int, C.c_void_p, C.c_size_t]
         self._plans: dict = {}
 
@@ -128,6 +131,21 @@ class Oracle:
     # ---- IIR -----------------------------------------------------------------------
     def iir(self, m: int = 4) -> "OracleIir":
         return OracleIir(self, m)
+
+    # ---- FIR (README.md:16 TODO in the reference: no reference code, pinned to scipy) -----------
+    def fir_design(self, taps: int, filter_type: int, f0: float, fs: float, q: float = 0.0, gain_in: float = 1.0):
+        h = np.zeros(taps)
+        if self.lib.sdsp_oracle_fir_design(taps, filter_type, f0, fs, q, gain_in, h.ctypes.data):
+            raise ValueError("fir_design: bad arguments")
+        return h
+
+    def fir_process(self, h, data, mem=None):
+        """returns (filtered copy, final history); mem = previous inputs, newest first (taps-1 values)"""
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        a = np.array(data, dtype=np.float64, order="C", copy=True)
+        m = np.zeros(max(h.size - 1, 1)) if mem is None else np.array(mem, dtype=np.float64, copy=True)
+        self.lib.sdsp_oracle_fir_process(h.size, h.ctypes.data, m.ctypes.data, a.ctypes.data, a.size)
+        return a, m[: h.size - 1]
 
     def __del__(self):
         try:

@@ -591,3 +591,65 @@ int sdsp_oracle_iir_process(sdsp_oracle_iir *f, int kind, double *data, size_t n
             MEM(f, j, i) = y[j][i];
     return 0;
 }
+
+/*
+ * FIR filter.  NOT a restatement of reference code: the reference lists it as a TODO (README.md:16).
+ * Parity with the reference is UNPINNED; the design is pinned to scipy.signal.firwin (Hamming window)
+ * and the filter to scipy.signal.lfilter in tests/test_oracle_fir.py.
+ * filter_type uses filter_type.h:6's values (1 lp, 2 hp, 3 bp) plus 4 = band stop.
+ */
+static double sinc_pi(double x)
+{
+    return x == 0 ? 1.0 : sin(M_PI * x) / (M_PI * x);
+}
+
+int sdsp_oracle_fir_design(unsigned taps, int filter_type, double f0, double fs, double q, double gain_in,
+                           double *h)
+{
+    if (taps == 0 || !h || filter_type < 1 || filter_type > 4)
+        return -1;
+    if ((filter_type == 2 || filter_type == 4) && taps % 2 == 0)
+        return -1; /* would need a zero at fs/2 */
+    const double nyq = fs / 2;
+    double edge[4];
+    unsigned ne = 0;
+    switch (filter_type) {
+    case 1: edge[ne++] = 0; edge[ne++] = f0 / nyq; break;
+    case 2: edge[ne++] = f0 / nyq; edge[ne++] = 1; break;
+    case 3: edge[ne++] = (f0 - f0 / (2 * q)) / nyq; edge[ne++] = (f0 + f0 / (2 * q)) / nyq; break;
+    default:
+        edge[ne++] = 0; edge[ne++] = (f0 - f0 / (2 * q)) / nyq;
+        edge[ne++] = (f0 + f0 / (2 * q)) / nyq; edge[ne++] = 1;
+        break;
+    }
+    const double alpha = 0.5 * (taps - 1);
+    for (unsigned i = 0; i < taps; i++) {
+        const double m = i - alpha;
+        double v = 0;
+        for (unsigned e = 0; e < ne; e += 2)
+            v += edge[e + 1] * sinc_pi(edge[e + 1] * m) - edge[e] * sinc_pi(edge[e] * m);
+        h[i] = v * (taps == 1 ? 1.0 : 0.54 - 0.46 * cos(2 * M_PI * i / (taps - 1)));
+    }
+    const double at = edge[0] == 0 ? 0.0 : (edge[1] == 1 ? 1.0 : 0.5 * (edge[0] + edge[1]));
+    double s = 0;
+    for (unsigned i = 0; i < taps; i++)
+        s += h[i] * cos(M_PI * (i - alpha) * at);
+    for (unsigned i = 0; i < taps; i++)
+        h[i] = h[i] / s * gain_in;
+    return 0;
+}
+
+void sdsp_oracle_fir_process(unsigned taps, const double *h, double *mem, double *data, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double x = data[i];
+        double acc = h[0] * x;
+        for (unsigned k = 1; k < taps; k++)
+            acc = acc + h[k] * mem[k - 1];
+        for (unsigned k = taps - 1; k > 1; k--)
+            mem[k - 1] = mem[k - 2];
+        if (taps > 1)
+            mem[0] = x;
+        data[i] = acc;
+    }
+}

@@ -67,6 +67,13 @@ void sdsp_oracle_iir_preload_filter(sdsp_oracle_iir *f, double value);
 /* kind 0: casc_2o_iir::process (reads b); 1/2/3: casc_2o_iir_{lp,hp,bp}::process (b folded) */
 int sdsp_oracle_iir_process(sdsp_oracle_iir *f, int kind, double *data, size_t n);
 
+/* ---- FIR filter: README.md:16 TODO, NO reference code -> parity with the reference unpinned; pinned to
+ * scipy.signal.firwin / lfilter in tests/test_oracle_fir.py ---- */
+int sdsp_oracle_fir_design(unsigned taps, int filter_type, double f0, double fs, double q, double gain_in,
+                           double *h);
+/* y[n] = sum_k h[k] x[n-k], ascending k, in place; mem[j] = x[n-1-j] (taps-1 values), updated */
+void sdsp_oracle_fir_process(unsigned taps, const double *h, double *mem, double *data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

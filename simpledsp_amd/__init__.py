@@ -9,6 +9,7 @@ from ._lib import (F32, F64, FORWARD, REVERSE, IIR_GENERIC, IIR_LP, IIR_HP, IIR_
 from .fft import (FftPlan, RfftPlan, fft_radix2, fft_radix4, forward_fft, reverse_fft, log2, log4, isPowerOf2,
                   isPowerOf4, digit_reverse, calc_swap_lookup, calc_twiddles, calc_wCoeffs)
 from .iir import casc_2o_iir, casc_2o_iir_lp, casc_2o_iir_hp, casc_2o_iir_bp
+from .fir import fir_filter
 
 
 class filter_type:  # filter_type.h:6

@@ -100,6 +100,12 @@ struct sdsp_hip_iir_plan {
     double b[3 * SDSP_HIP_MAX_SECTIONS] = {};
 };
 
+struct sdsp_hip_fir_plan {
+    uint32_t taps = 0;
+    int precision = 0, device = 0, variant = 0;
+    void *h_dev = nullptr;
+};
+
 namespace
 {
 // largest power-of-two column count whose padded tile fits the LDS budget
@@ -884,5 +890,134 @@ int sdsp_hip_iir_process_sharded(sdsp_hip_iir_plan *const *plans, int n_plans, v
         if (rcs[g])
             return fail(rcs[g], errs[g]);
     return SDSP_HIP_OK;
+}
+// ------------------------------------------------------------------ FIR banks
+
+int sdsp_hip_fir_plan_create(sdsp_hip_fir_plan **out, uint32_t taps, const double *h, int precision, int device)
+{
+    if (!out)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
+    *out = nullptr;
+    if (taps == 0 || taps > SDSP_HIP_FIR_MAX_TAPS)
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "taps must be in [1, SDSP_HIP_FIR_MAX_TAPS]");
+    if (!h)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "coefficient pointer is null");
+    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32 or SDSP_HIP_F64");
+    if (int rc = use_device(device))
+        return rc;
+    auto *p = new sdsp_hip_fir_plan();
+    p->taps = taps;
+    p->precision = precision;
+    p->device = device;
+    hipError_t e;
+    if (precision == SDSP_HIP_F64) {
+        e = hipMalloc(&p->h_dev, taps * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpy(p->h_dev, h, taps * sizeof(double), hipMemcpyHostToDevice);
+    } else {
+        std::vector<float> hf(h, h + taps);
+        e = hipMalloc(&p->h_dev, taps * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMemcpy(p->h_dev, hf.data(), taps * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(p->h_dev);
+        delete p;
+        return hip_fail(e, "fir coefficients");
+    }
+    *out = p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fir_plan_destroy(sdsp_hip_fir_plan *p)
+{
+    if (!p)
+        return SDSP_HIP_OK;
+    if (p->h_dev && use_device(p->device) == SDSP_HIP_OK)
+        (void)hipFree(p->h_dev);
+    delete p;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fir_state_bytes(const sdsp_hip_fir_plan *p, uint64_t channels, uint64_t *bytes)
+{
+    if (!p || !bytes)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    *bytes = static_cast<uint64_t>(p->taps - 1) * channels * (p->precision == SDSP_HIP_F64 ? 8 : 4);
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fir_plan_set_variant(sdsp_hip_fir_plan *p, int variant)
+{
+    if (!p || variant < 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "bad argument");
+    p->variant = variant;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fir_process(sdsp_hip_fir_plan *p, void *data, uint64_t channels, uint64_t samples, uint64_t stride,
+                         void *state, void *stream)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (stride < samples && channels > 1)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "stride must be >= samples");
+    if (int rc = use_device(p->device))
+        return rc;
+    fir_args a{};
+    a.data = data;
+    a.state = p->taps > 1 ? state : nullptr;
+    a.h = p->h_dev;
+    a.channels = channels;
+    a.samples = samples;
+    a.stride = stride;
+    a.taps = p->taps;
+    return launch_fir(p->precision, a, p->variant, stream);
+}
+
+int sdsp_hip_fir_process_host(sdsp_hip_fir_plan *p, void *host_data, uint64_t channels, uint64_t samples,
+                              uint64_t stride, void *host_state)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (channels == 0 || samples == 0)
+        return SDSP_HIP_OK;
+    if (!host_data)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
+    if (int rc = use_device(p->device))
+        return rc;
+    const size_t rs = p->precision == SDSP_HIP_F64 ? 8 : 4;
+    const size_t data_bytes = ((channels - 1) * stride + samples) * rs;
+    uint64_t state_bytes = 0;
+    sdsp_hip_fir_state_bytes(p, channels, &state_bytes);
+    const bool with_state = host_state && state_bytes;
+    void *d = nullptr, *s = nullptr;
+    HIP_TRY(hipMalloc(&d, data_bytes));
+    int rc = SDSP_HIP_OK;
+    hipError_t e = hipMemcpy(d, host_data, data_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && with_state) {
+        e = hipMalloc(&s, state_bytes);
+        if (e == hipSuccess)
+            e = hipMemcpy(s, host_state, state_bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess)
+        rc = hip_fail(e, "fir host staging");
+    if (!rc)
+        rc = sdsp_hip_fir_process(p, d, channels, samples, stride, s, nullptr);
+    if (!rc) {
+        e = hipMemcpy(host_data, d, data_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && with_state)
+            e = hipMemcpy(host_state, s, state_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = hip_fail(e, "fir host read-back");
+    }
+    (void)hipFree(d);
+    (void)hipFree(s);
+    return rc;
 }
 }

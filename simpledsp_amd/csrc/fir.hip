@@ -1,0 +1,322 @@
+// fir.hip -- batched direct-form FIR filter bank for MI355X (gfx950).  SURVEY 8(f)-4: the reference
+// lists "FIR filter" as a TODO (README.md:16) and has no code for it; the recurrence implemented here
+// is the textbook y[n] = sum_{k=0}^{T-1} h[k] x[n-k], accumulated in ascending k (acc = h[0] x[n], then
+// one multiply and one add per tap -- unfused in f64 so the result is bit-identical to the CPU oracle,
+// fused multiply-add in f32).  Layout, ownership and streaming semantics follow the IIR bank
+// (casc_2o_iir.h:36-80 as batched in iir.hip): channel-major rows filtered in place, per-channel history
+// read at entry and written at exit.
+//
+// HBM-bound: 8 B (f32) / 16 B (f64) per sample.  One group of `tpr` threads owns one channel row and
+// walks it block by block (16*tpr samples).  A block is loaded with 16-byte accesses, a wave covering
+// 1 KiB of the row per instruction, into a padded LDS line that also keeps the previous T-1 inputs in
+// front of it; each thread then produces 16 CONSECUTIVE outputs from a sliding register window
+// (one 16-sample LDS block read per 16 taps), the outputs go back through the same LDS line and leave
+// with the same coalesced shape.  Because a row is owned by one group, in-place operation needs no
+// second buffer.
+#include "sdsp_hip_internal.h"
+
+#include <hip/hip_runtime.h>
+
+namespace sdsp_hip
+{
+namespace
+{
+constexpr int kThreads = 256;
+constexpr int kOut = 16; // outputs per thread = LDS block length
+
+template <typename R> struct vec_of;
+template <> struct vec_of<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int lanes = 4;
+    static constexpr int pad = 4; // elements of padding after every 16-element block (80-B pitch)
+};
+template <> struct vec_of<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int lanes = 2;
+    static constexpr int pad = 2; // 144-B pitch
+};
+
+template <typename R> __device__ __forceinline__ R mul_add(R h, R x, R acc);
+template <> __device__ __forceinline__ float mul_add<float>(float h, float x, float acc) { return __builtin_fmaf(h, x, acc); }
+template <> __device__ __forceinline__ double mul_add<double>(double h, double x, double acc)
+{
+    return acc + h * x; // built with -ffp-contract=off: separate multiply and add, as the oracle does
+}
+
+// padded LDS position of element p of a line (p counts from the start of the history region)
+template <typename R> __device__ __forceinline__ uint32_t slot(uint32_t p) { return p + (p >> 4) * vec_of<R>::pad; }
+
+template <typename R> __device__ __forceinline__ void read_block(const R *line, uint32_t blk, R (&dst)[kOut])
+{
+    using V = typename vec_of<R>::type;
+    constexpr int L = vec_of<R>::lanes;
+    const V *src = reinterpret_cast<const V *>(line + blk * (kOut + vec_of<R>::pad));
+#pragma unroll
+    for (int i = 0; i < kOut / L; i++) {
+        V v = src[i];
+#pragma unroll
+        for (int j = 0; j < L; j++)
+            dst[i * L + j] = v[j];
+    }
+}
+
+// 16 taps h[k0 .. k0+16) applied to 16 outputs.  win[0..16) = the block 16 samples earlier,
+// win[16..32) = the block the oldest of these taps starts in.  `count` < 16 only in the last chunk.
+template <typename R, bool FIRST, bool PARTIAL>
+__device__ __forceinline__ void taps16(const R *__restrict__ h, uint32_t k0, uint32_t count, const R (&win)[2 * kOut], R (&acc)[kOut])
+{
+#pragma unroll
+    for (int kk = 0; kk < kOut; kk++) {
+        if (!PARTIAL || static_cast<uint32_t>(kk) < count) { // wave-uniform
+            const R hk = h[k0 + kk];
+#pragma unroll
+            for (int r = 0; r < kOut; r++) {
+                if (FIRST && kk == 0)
+                    acc[r] = hk * win[kOut + r];
+                else
+                    acc[r] = mul_add<R>(hk, win[kOut + r - kk], acc[r]);
+            }
+        }
+    }
+}
+
+struct fir_kargs {
+    void *data;
+    void *state;
+    const void *h;
+    uint64_t channels, samples, stride;
+    uint32_t taps;
+    uint32_t tpr_log2; // threads per row
+    uint32_t hist;     // history region length in elements: 16 * ceil(taps / 16)
+    uint32_t vec_ok;   // rows 16-byte aligned
+};
+
+template <typename R, bool NT> __global__ __launch_bounds__(kThreads) void sdsp_fir_kernel(fir_kargs a)
+{
+    using V = typename vec_of<R>::type;
+    constexpr int L = vec_of<R>::lanes;
+    constexpr int VPT = kOut / L; // vectors per thread per block
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+
+    const uint32_t tpr = 1u << a.tpr_log2;
+    const uint32_t row = threadIdx.x >> a.tpr_log2;
+    const uint32_t t = threadIdx.x & (tpr - 1);
+    const uint32_t rows_per_wg = kThreads >> a.tpr_log2;
+    const uint64_t ch = static_cast<uint64_t>(blockIdx.x) * rows_per_wg + row;
+    const bool live = ch < a.channels;
+    const uint32_t block_len = tpr * kOut;
+    const uint32_t line_elems = slot<R>(a.hist + block_len);
+    R *line = reinterpret_cast<R *>(lds_raw) + static_cast<size_t>(row) * line_elems;
+    const R *__restrict__ h = static_cast<const R *>(a.h);
+    R *rowp = static_cast<R *>(a.data) + (live ? ch : 0) * a.stride;
+    const uint32_t T1 = a.taps - 1;
+    R *statep = a.state ? static_cast<R *>(a.state) + (live ? ch : 0) * T1 : nullptr;
+
+    // history: element e = -1-j of the stream is state[j]; it sits at line position hist-1-j
+    for (uint32_t j = t; j < a.hist; j += tpr) {
+        R v = R(0);
+        if (live && statep && j < T1)
+            v = statep[j];
+        line[slot<R>(a.hist - 1 - j)] = v;
+    }
+
+    const uint32_t nfull = a.taps / kOut, rem = a.taps % kOut;
+    for (uint64_t s0 = 0; s0 < a.samples; s0 += block_len) {
+        const uint64_t left = a.samples - s0;
+        const uint32_t len = left < block_len ? static_cast<uint32_t>(left) : block_len;
+        const bool whole = len == block_len && a.vec_ok;
+        R *blk = rowp + s0;
+
+        // ---- load the block: vector i of thread t is elements (i*tpr + t)*L ...
+        if (live) {
+            if (whole) {
+                V v[VPT];
+#pragma unroll
+                for (int i = 0; i < VPT; i++) {
+                    const V *src = reinterpret_cast<const V *>(blk) + (i * tpr + t);
+                    v[i] = NT ? __builtin_nontemporal_load(src) : *src;
+                }
+#pragma unroll
+                for (int i = 0; i < VPT; i++)
+                    *reinterpret_cast<V *>(line + slot<R>(a.hist + (i * tpr + t) * L)) = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPT; i++)
+#pragma unroll
+                    for (int j = 0; j < L; j++) {
+                        const uint32_t e = (i * tpr + t) * L + j;
+                        line[slot<R>(a.hist + e)] = e < len ? blk[e] : R(0);
+                    }
+            }
+        }
+        __syncthreads();
+
+        // ---- 16 consecutive outputs per thread; tap chunk kc reads blocks (mine - kc) and (mine - kc - 1)
+        R acc[kOut];
+        {
+            const uint32_t mine = (a.hist >> 4) + t;
+            R win[2 * kOut];
+            {
+                R cur[kOut];
+                read_block<R>(line, mine, cur);
+#pragma unroll
+                for (int i = 0; i < kOut; i++)
+                    win[kOut + i] = cur[i];
+            }
+            uint32_t kc = 0;
+            if (nfull) {
+                R prev[kOut];
+                read_block<R>(line, mine - 1, prev);
+#pragma unroll
+                for (int i = 0; i < kOut; i++)
+                    win[i] = prev[i];
+                taps16<R, true, false>(h, 0, kOut, win, acc);
+                for (kc = 1; kc < nfull; kc++) {
+#pragma unroll
+                    for (int i = 0; i < kOut; i++)
+                        win[kOut + i] = win[i];
+                    read_block<R>(line, mine - kc - 1, prev);
+#pragma unroll
+                    for (int i = 0; i < kOut; i++)
+                        win[i] = prev[i];
+                    taps16<R, false, false>(h, kc * kOut, kOut, win, acc);
+                }
+                if (rem) {
+#pragma unroll
+                    for (int i = 0; i < kOut; i++)
+                        win[kOut + i] = win[i];
+                }
+            }
+            if (rem) {
+                R prev[kOut];
+                read_block<R>(line, mine - kc - 1, prev);
+#pragma unroll
+                for (int i = 0; i < kOut; i++)
+                    win[i] = prev[i];
+                if (nfull)
+                    taps16<R, false, true>(h, kc * kOut, rem, win, acc);
+                else
+                    taps16<R, true, true>(h, 0, rem, win, acc);
+            }
+        }
+        __syncthreads();
+
+        // ---- carry the newest inputs: to the state buffer after the last block, else to the history region
+        const bool last = s0 + block_len >= a.samples;
+        if (last) {
+            if (live && statep)
+                for (uint32_t j = t; j < T1; j += tpr)
+                    statep[j] = line[slot<R>(a.hist + len - 1 - j)]; // len-1-j >= -hist always
+        } else {
+            // block_len >= hist (host guarantees), so source and destination do not overlap
+            for (uint32_t j = t; j < a.hist; j += tpr)
+                line[slot<R>(j)] = line[slot<R>(block_len + j)];
+        }
+        __syncthreads();
+
+        // ---- outputs back through the line (block region), then out with the load's shape
+        {
+            V *dst = reinterpret_cast<V *>(line + slot<R>(a.hist + t * kOut));
+#pragma unroll
+            for (int i = 0; i < VPT; i++) {
+                V v;
+#pragma unroll
+                for (int j = 0; j < L; j++)
+                    v[j] = acc[i * L + j];
+                dst[i] = v;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < VPT; i++) {
+                    const V v = *reinterpret_cast<const V *>(line + slot<R>(a.hist + (i * tpr + t) * L));
+                    V *dstg = reinterpret_cast<V *>(blk) + (i * tpr + t);
+                    if (NT)
+                        __builtin_nontemporal_store(v, dstg);
+                    else
+                        *dstg = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPT; i++)
+#pragma unroll
+                    for (int j = 0; j < L; j++) {
+                        const uint32_t e = (i * tpr + t) * L + j;
+                        if (e < len)
+                            blk[e] = line[slot<R>(a.hist + e)];
+                    }
+            }
+        }
+        // the next block's LDS writes touch exactly the positions this thread just read; the history
+        // region was written before the barrier above
+    }
+}
+
+uint32_t ceil_log2(uint64_t v)
+{
+    uint32_t l = 0;
+    while ((1ull << l) < v)
+        l++;
+    return l;
+}
+} // namespace
+
+size_t fir_lds_bytes(int precision, uint32_t taps, uint32_t tpr_log2)
+{
+    const uint32_t hist = kOut * ((taps + kOut - 1) / kOut);
+    const uint32_t elems = hist + (kOut << tpr_log2);
+    const uint32_t pad = precision == SDSP_HIP_F64 ? vec_of<double>::pad : vec_of<float>::pad;
+    const size_t line = elems + (elems >> 4) * pad;
+    return line * (kThreads >> tpr_log2) * (precision == SDSP_HIP_F64 ? 8 : 4);
+}
+
+int launch_fir(int precision, const fir_args &fa, int variant, void *stream_v)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const size_t rs = precision == SDSP_HIP_F64 ? 8 : 4;
+    fir_kargs k{};
+    k.data = fa.data;
+    k.state = fa.state;
+    k.h = fa.h;
+    k.channels = fa.channels;
+    k.samples = fa.samples;
+    k.stride = fa.stride;
+    k.taps = fa.taps;
+    k.hist = kOut * ((fa.taps + kOut - 1) / kOut);
+    // threads per row: enough for the row (up to 256), never fewer than the history needs
+    uint32_t l = ceil_log2((fa.samples + kOut - 1) / kOut);
+    const uint32_t lmin = ceil_log2(k.hist / kOut);
+    if (l < lmin)
+        l = lmin;
+    if (l > 8)
+        l = 8;
+    if (lmin > 8)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many taps");
+    k.tpr_log2 = l;
+    k.vec_ok = (reinterpret_cast<uintptr_t>(fa.data) % 16 == 0 && (fa.stride * rs) % 16 == 0) ? 1 : 0;
+    const size_t lds = fir_lds_bytes(precision, fa.taps, l);
+    const uint32_t rows_per_wg = kThreads >> l;
+    const uint64_t grid = (fa.channels + rows_per_wg - 1) / rows_per_wg;
+    if (grid > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    const bool nt = variant == 0;
+    auto run = [&](auto kernel) -> int {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds));
+            if (e != hipSuccess)
+                return fail(SDSP_HIP_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kThreads), lds, stream, k);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return fail(SDSP_HIP_ERR_HIP, std::string("fir launch: ") + hipGetErrorString(e));
+        return SDSP_HIP_OK;
+    };
+    if (precision == SDSP_HIP_F64)
+        return nt ? run(sdsp_fir_kernel<double, true>) : run(sdsp_fir_kernel<double, false>);
+    return nt ? run(sdsp_fir_kernel<float, true>) : run(sdsp_fir_kernel<float, false>);
+}
+} // namespace sdsp_hip

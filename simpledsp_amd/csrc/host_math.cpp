@@ -183,6 +183,61 @@ int design_bs(uint32_t m, double f0, double fs, double q, double gain_in, double
     return SDSP_HIP_OK;
 }
 
+// FIR design -- the reference's README.md:16 TODO; no reference code.  Windowed-sinc (Hamming) design,
+// the same construction as scipy.signal.firwin (which the tests pin it to): ideal band responses
+// sum(right sinc(right m) - left sinc(left m)) over the pass bands, times the symmetric Hamming window,
+// scaled to unit gain at DC / Nyquist / the band centre.  lp, hp take the cutoff f0; bp, bs take
+// centre f0 and q with edges f0 -+ f0/(2q) (width f0/q as in set_bp_coeff, without frequency warping).
+int design_fir(uint32_t taps, int filter_type, double f0, double fs, double q, double gain_in, double *h)
+{
+    if (taps == 0 || taps > SDSP_HIP_FIR_MAX_TAPS)
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "taps must be in [1, SDSP_HIP_FIR_MAX_TAPS]");
+    if (!h)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null output pointer");
+    const double nyq = fs / 2;
+    double lo = 0, hi = 0; // the band that defines the filter, as fractions of Nyquist
+    bool pass_zero = false;
+    switch (filter_type) {
+    case SDSP_HIP_FILTER_LOW_PASS: lo = 0; hi = f0 / nyq; pass_zero = true; break;
+    case SDSP_HIP_FILTER_HIGH_PASS: lo = f0 / nyq; hi = 1; pass_zero = false; break;
+    case SDSP_HIP_FILTER_BAND_PASS: lo = (f0 - f0 / (2 * q)) / nyq; hi = (f0 + f0 / (2 * q)) / nyq; pass_zero = false; break;
+    case SDSP_HIP_FILTER_BAND_STOP: lo = (f0 - f0 / (2 * q)) / nyq; hi = (f0 + f0 / (2 * q)) / nyq; pass_zero = true; break;
+    default: return fail(SDSP_HIP_ERR_INVALID_ARG, "filter_type must be low_pass, high_pass, band_pass or band_stop");
+    }
+    const bool band = filter_type == SDSP_HIP_FILTER_BAND_PASS || filter_type == SDSP_HIP_FILTER_BAND_STOP;
+    if (!(fs > 0) || !(band ? (lo > 0 && hi < 1 && lo < hi) : (f0 > 0 && f0 < nyq)))
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "cutoff frequencies must lie strictly between 0 and fs/2");
+    const bool pass_nyquist = filter_type == SDSP_HIP_FILTER_HIGH_PASS || filter_type == SDSP_HIP_FILTER_BAND_STOP;
+    if (pass_nyquist && taps % 2 == 0)
+        return fail(SDSP_HIP_ERR_INVALID_SIZE, "a filter that passes fs/2 needs an odd number of taps");
+    // pass bands as (left, right) pairs
+    double bands[2][2];
+    int nb = 0;
+    if (filter_type == SDSP_HIP_FILTER_LOW_PASS) { bands[nb][0] = 0; bands[nb++][1] = hi; }
+    else if (filter_type == SDSP_HIP_FILTER_HIGH_PASS) { bands[nb][0] = lo; bands[nb++][1] = 1; }
+    else if (filter_type == SDSP_HIP_FILTER_BAND_PASS) { bands[nb][0] = lo; bands[nb++][1] = hi; }
+    else { bands[nb][0] = 0; bands[nb++][1] = lo; bands[nb][0] = hi; bands[nb++][1] = 1; }
+    (void)pass_zero;
+    auto sinc = [](double x) { return x == 0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x); };
+    const double alpha = 0.5 * (taps - 1);
+    for (uint32_t i = 0; i < taps; i++) {
+        const double m = i - alpha;
+        double v = 0;
+        for (int bnd = 0; bnd < nb; bnd++)
+            v += bands[bnd][1] * sinc(bands[bnd][1] * m) - bands[bnd][0] * sinc(bands[bnd][0] * m);
+        const double w = taps == 1 ? 1.0 : 0.54 - 0.46 * std::cos(2 * M_PI * i / (taps - 1));
+        h[i] = v * w;
+    }
+    const double left = bands[0][0], right = bands[0][1];
+    const double scale_frequency = left == 0 ? 0.0 : (right == 1 ? 1.0 : 0.5 * (left + right));
+    double s = 0;
+    for (uint32_t i = 0; i < taps; i++)
+        s += h[i] * std::cos(M_PI * (i - alpha) * scale_frequency);
+    for (uint32_t i = 0; i < taps; i++)
+        h[i] = h[i] / s * gain_in;
+    return SDSP_HIP_OK;
+}
+
 // preload_filter: casc_2o_iir.h:197-214.  DC propagates section to section only for low_pass
 // (and band_stop, which also passes DC; not in the reference).
 int preload(uint32_t m, int filter_type, const double *a, const double *b, double gain,
@@ -278,6 +333,10 @@ int sdsp_hip_iir_design_bp(uint32_t m, double f0, double fs, double q, double ga
 int sdsp_hip_iir_design_bs(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain)
 {
     return design_bs(m, f0, fs, q, gain_in, a, b, gain);
+}
+int sdsp_hip_fir_design(uint32_t taps, int filter_type, double f0, double fs, double q, double gain_in, double *h)
+{
+    return design_fir(taps, filter_type, f0, fs, q, gain_in, h);
 }
 int sdsp_hip_iir_preload(uint32_t m, int filter_type, const double *a, const double *b, double gain, double value, double *mem)
 {

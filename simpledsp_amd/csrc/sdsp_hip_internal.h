@@ -17,6 +17,8 @@ void make_twiddles(uint32_t n, int direction, std::vector<double> &out);
 int design_lp(uint32_t m, double f0, double fs, double gain_in, double *a, double *b, double *gain);
 int design_hp(uint32_t m, double f0, double fs, double gain_in, double *a, double *b, double *gain);
 int design_bp(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain);
+int design_bs(uint32_t m, double f0, double fs, double q, double gain_in, double *a, double *b, double *gain);
+int design_fir(uint32_t taps, int filter_type, double f0, double fs, double q, double gain_in, double *h);
 int preload(uint32_t m, int filter_type, const double *a, const double *b, double gain, double value,
             double *mem);
 
@@ -113,4 +115,14 @@ struct iir_args {
 };
 int launch_iir(int precision, const iir_args &a, int variant, void *stream);
 int launch_iir_interleaved(int precision, const iir_args &a, int variant, void *stream);
+
+// FIR bank
+struct fir_args {
+    void *data;
+    void *state;   // nullable; channels x (taps-1), newest first
+    const void *h; // device, plan precision, `taps` values
+    uint64_t channels, samples, stride;
+    uint32_t taps;
+};
+int launch_fir(int precision, const fir_args &a, int variant, void *stream);
 } // namespace sdsp_hip

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sdsp/casc_2o_iir.h"
+#include "sdsp/fir.h"
 #include "sdsp/fft.h"
 
 static int g_pass = 0, g_fail = 0;
@@ -435,6 +436,69 @@ void test_band_stop()
     REQUIRE(worst < 1e-9);
 }
 
+// FIR filter (the reference's README.md:16 TODO): impulse response == taps, block == whole, bank == single
+void test_fir()
+{
+    constexpr double fs{ 100e3 }, f0{ 10e3 };
+    sdsp::fir_filter<31> f;
+    f.set_lp_coeff(f0, fs);
+    REQUIRE(f.type() == sdsp::filter_type::low_pass);
+    double dc = 0;
+    for (double v : f.coeff())
+        dc += v;
+    REQUIRE(std::abs(dc - 1.0) < 1e-12);
+    for (size_t i = 0; i < 31; i++)
+        REQUIRE(f.coeff()[i] == f.coeff()[30 - i]); // linear phase
+    std::array<double, 64> imp{};
+    imp[0] = 1.0;
+    f.process(imp.begin(), imp.end());
+    bool same = true;
+    for (size_t i = 0; i < 64; i++)
+        same = same && imp[i] == (i < 31 ? f.coeff()[i] : 0.0);
+    REQUIRE(same);
+
+    std::mt19937_64 gen(11);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::array<double, 1000> x{}, y{};
+    for (auto &v : x)
+        v = nd(gen);
+    y = x;
+    sdsp::fir_filter<31> whole, blocks;
+    whole.copy_coeff_from(f);
+    blocks.copy_coeff_from(f);
+    whole.process(x.begin(), x.end());
+    for (size_t i = 0; i < y.size(); i += 40)
+        blocks.process(y.begin() + static_cast<std::ptrdiff_t>(i), y.begin() + static_cast<std::ptrdiff_t>(std::min(i + 40, y.size())));
+    REQUIRE(x == y);
+
+    sdsp::fir_filter<31> pre;
+    pre.copy_coeff_from(f);
+    pre.preload_filter(10.0);
+    std::array<double, 128> steady;
+    steady.fill(10.0);
+    pre.process(steady.begin(), steady.end());
+    double worst = 0;
+    for (double v : steady)
+        worst = std::max(worst, std::abs(v - 10.0));
+    REQUIRE(worst < 1e-12);
+
+    // the bank on three channels == three single-stream filters, bit for bit (f64)
+    constexpr size_t C = 3, S = 500;
+    std::vector<double> bankdata(C * S);
+    for (auto &v : bankdata)
+        v = nd(gen);
+    std::vector<double> single = bankdata;
+    sdsp::fir_bank<31, double> bank(C);
+    bank.set_lp_coeff(f0, fs);
+    bank.process_host(bankdata.data(), S);
+    for (size_t c = 0; c < C; c++) {
+        sdsp::fir_filter<31> one;
+        one.set_lp_coeff(f0, fs);
+        one.process(single.begin() + static_cast<std::ptrdiff_t>(c * S), single.begin() + static_cast<std::ptrdiff_t>((c + 1) * S));
+    }
+    REQUIRE(bankdata == single);
+}
+
 void test_next_rows()
 {
     std::mt19937_64 gen(7);
@@ -542,6 +606,7 @@ int main(int argc, char **argv)
         test_batched_entries();
         test_next_rows();
         test_band_stop();
+        test_fir();
     } catch (const sdsp::hip_error &e) {
         std::printf("GPU path unavailable (no CPU fallback): %s (code %d)\n", e.what(), e.code());
         return 3;

@@ -101,6 +101,31 @@ def test_band_stop_design_matches_oracle_and_scipy(oracle, m):
     assert np.abs(mem - fo.mem).max() < 1e-10 and abs(mem[4, 0] - 10.0) < 1e-9
 
 
+def test_fir_design_matches_oracle_and_firwin(oracle):
+    """sdsp_hip_fir_design (README.md:16 TODO, no reference code) against the oracle's independent C
+    version and scipy.signal.firwin; error codes for what firwin rejects."""
+    import scipy.signal
+    from test_oracle_fir import FIR_CASES
+    lib = sd.load()
+    for taps, ftype, f0, fs, q, kw in FIR_CASES:
+        f = sd.fir_filter(taps)
+        {1: f.set_lp_coeff, 2: f.set_hp_coeff}.get(ftype, lambda a, b, g=1.0: None)(f0, fs)
+        if ftype == 3:
+            f.set_bp_coeff(f0, fs, q)
+        if ftype == 4:
+            f.set_bs_coeff(f0, fs, q)
+        assert np.abs(f.m_coeff - scipy.signal.firwin(taps, fs=fs, **kw)).max() < 1e-15
+        assert np.abs(f.m_coeff - oracle.fir_design(taps, ftype, f0, fs, q)).max() < 1e-15
+    h = np.zeros(64)
+    assert lib.sdsp_hip_fir_design(64, 2, 10e3, 100e3, 0.0, 1.0, h.ctypes.data) == L.ERR_INVALID_SIZE  # even taps, passes fs/2
+    assert lib.sdsp_hip_fir_design(0, 1, 10e3, 100e3, 0.0, 1.0, h.ctypes.data) == L.ERR_INVALID_SIZE
+    assert lib.sdsp_hip_fir_design(31, 1, 60e3, 100e3, 0.0, 1.0, h.ctypes.data) == L.ERR_INVALID_ARG   # beyond fs/2
+    assert lib.sdsp_hip_fir_design(31, 0, 10e3, 100e3, 0.0, 1.0, h.ctypes.data) == L.ERR_INVALID_ARG
+    plan = C.c_void_p()
+    assert lib.sdsp_hip_fir_plan_create(C.byref(plan), 0, h.ctypes.data, L.F32, 0) == L.ERR_INVALID_SIZE
+    assert lib.sdsp_hip_fir_plan_create(C.byref(plan), 5000, h.ctypes.data, L.F32, 0) == L.ERR_INVALID_SIZE
+
+
 def test_design_matches_reference_fixtures(iir_golden):
     for tag in iir_golden["csv_names"]:
         ftype, fs, f0, q = iir_golden[f"{tag}__params"]
@@ -151,6 +176,9 @@ def test_no_cpu_fallback_without_a_device():
         sd.fft_radix2(np.zeros(64, np.complex128))
     n = C.c_int(-1)
     assert sd.load().sdsp_hip_device_count(C.byref(n)) == 0 and n.value == 0
+    plan = C.c_void_p()
+    h = np.ones(8)
+    assert sd.load().sdsp_hip_fir_plan_create(C.byref(plan), 8, h.ctypes.data, L.F64, 0) == L.ERR_NO_DEVICE
 
 
 def test_product_never_imports_the_oracle():
