@@ -447,8 +447,10 @@ void test_fir()
     for (double v : f.coeff())
         dc += v;
     REQUIRE(std::abs(dc - 1.0) < 1e-12);
+    double asym = 0;
     for (size_t i = 0; i < 31; i++)
-        REQUIRE(f.coeff()[i] == f.coeff()[30 - i]); // linear phase
+        asym = std::max(asym, std::abs(f.coeff()[i] - f.coeff()[30 - i]));
+    REQUIRE(asym < 1e-15); // linear phase (the window's cos() is not bit-symmetric, as in scipy's firwin)
     std::array<double, 64> imp{};
     imp[0] = 1.0;
     f.process(imp.begin(), imp.end());

@@ -58,6 +58,29 @@ def test_f64_bit_exact_against_oracle(sd, torch_cuda, oracle, taps, channels, sa
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("taps,precision", [(1000, "f64"), (4096, "f64"), (4096, "f32")])
+def test_long_filters(sd, torch_cuda, oracle, taps, precision):
+    """SDSP_HIP_FIR_MAX_TAPS and the > 64 KiB LDS line (f64, 4096 taps: 72 KiB)."""
+    rng = np.random.default_rng(taps)
+    h = rng.standard_normal(taps) / np.sqrt(taps)
+    f64 = precision == "f64"
+    x = rng.standard_normal((3, 9000)).astype(np.float64 if f64 else np.float32)
+    bank = sd.fir_filter(taps, 3, sd.F64 if f64 else sd.F32)
+    bank.set_coeff(h)
+    got = _run(torch_cuda, bank, x)
+    if f64:
+        assert np.array_equal(got[1], oracle.fir_process(h, x[1])[0])
+    else:
+        h32 = h.astype(np.float32).astype(np.float64)
+        # a sequential f32 sum of T terms carries ~sqrt(T) eps: 64 * 1.19e-7 = 7.6e-6 at T = 4096 (the 1e-6 of
+        # SURVEY 8(d) is stated for the short filters of the other tests)
+        assert rel_max_err(got[1], oracle.fir_process(h32, x[1].astype(np.float64))[0]) < np.sqrt(taps) * 1.19e-7
+    with pytest.raises(sd.SdspHipError):
+        too_long = sd.fir_filter(4097, 1, sd.F32)
+        too_long.set_coeff(np.ones(4097))
+        too_long.process(torch_cuda.zeros((1, 16), device="cuda"))
+
+
 @pytest.mark.parametrize("taps,ftype", [(31, 1), (32, 1), (33, 2), (64, 3), (65, 4)])
 def test_designed_filters_f32_and_lfilter(sd, torch_cuda, oracle, taps, ftype):
     import scipy.signal
@@ -71,6 +94,10 @@ def test_designed_filters_f32_and_lfilter(sd, torch_cuda, oracle, taps, ftype):
     if ftype == 4:
         bank.set_bs_coeff(10e3, 100e3, 1.1)
     got = _run(torch_cuda, bank, x)
+    for variant in (1, 2, 3):  # default-policy, packed-FMA and one-FMA-per-tap kernels: same values
+        bank.reset()
+        bank.set_variant(variant)
+        assert np.array_equal(_run(torch_cuda, bank, x), got), variant
     h32 = bank.m_coeff.astype(np.float32).astype(np.float64)
     for c in (0, 7, 299):
         want = oracle.fir_process(h32, x[c].astype(np.float64))[0]

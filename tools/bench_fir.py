@@ -8,12 +8,13 @@ import simpledsp_amd as sd
 
 precision = sys.argv[1] if len(sys.argv) > 1 else "f32"
 taps_list = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 16, 32, 64, 128]
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
 f64 = precision == "f64"
 channels, samples = (1 << 19) if f64 else (1 << 20), 4096
 x = torch.randn((channels, samples), device="cuda", dtype=torch.float64 if f64 else torch.float32)
 rs = 8 if f64 else 4
 for taps in taps_list:
-    for variant in (0, 1):
+    for variant in variants:
         bank = sd.fir_filter(taps, channels, sd.F64 if f64 else sd.F32)
         bank.set_lp_coeff(10e3, 100e3)  # unit DC gain: repeated filtering stays bounded
         bank.set_variant(variant)
