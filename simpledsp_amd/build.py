@@ -34,6 +34,7 @@ SOURCES = {
     "fft1m.hip": ["-fno-slp-vectorize"],  # SLP packing cost 44-76 B/lane of scratch here
     "fft_reg.hip": ["-fno-slp-vectorize"],
     "fft_reg64.hip": ["-fno-slp-vectorize"],
+    "fft_big.hip": ["-fno-slp-vectorize"],
     "iir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "fir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],  # f64 taps: multiply then add, like the oracle
 }
@@ -57,7 +58,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    headers = [CSRC / "sdsp_hip_internal.h", CSRC / "fft_passes.h", ROOT / "include" / "sdsp_hip.h", Path(__file__)]
+    headers = [CSRC / "sdsp_hip_internal.h", CSRC / "fft_passes.h", CSRC / "fft32.h", ROOT / "include" / "sdsp_hip.h", Path(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

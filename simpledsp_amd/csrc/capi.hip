@@ -145,6 +145,21 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r2_f32(a, stream);
     }
 
+    // N = 8192 / 16384 / 32768 radix 2 f32: registers-resident single-pass kernel (fft_big.hip)
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
+        !p->real_mode && fft_big_supports(p->n, p->radix)) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->tw;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = rev;
+        a.nontemporal = 1;
+        return launch_fft_big_f32(a, stream);
+    }
+
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0) {
         fft_reg_args a;
         a.data = data;
@@ -666,7 +681,9 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->direction = p->direction;
     info->precision = p->precision;
     info->device = p->device;
-    info->hbm_passes = (p->path == PATH_FOUR_STEP || p->path == PATH_FFT1M) ? 2 : 1;
+    const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
+                     !p->real_mode && fft_big_supports(p->n, p->radix);
+    info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
     info->algorithmic_bytes = 2ull * p->n * esize(p->precision); // real plans: n complex = n_real floats, same bytes
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;
@@ -678,6 +695,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
+    if (big)
+        name = "sdsp_fft_big_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

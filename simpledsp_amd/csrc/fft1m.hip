@@ -26,111 +26,14 @@
 // the intermediate uses the default policy to stay in it.
 #include <hip/hip_runtime.h>
 
+#include "fft32.h"
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
 {
 namespace
 {
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float2 nt_load(const float2 *p)
-{
-    const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(p));
-    return float2{ v.x, v.y };
-}
-__device__ __forceinline__ void nt_store(float2 *p, float2 a)
-{
-    const v2f_t v = { a.x, a.y };
-    __builtin_nontemporal_store(v, reinterpret_cast<v2f_t *>(p));
-}
-// uniform base (SGPR pair) + 32-bit per-thread byte offset: the global_load/store "saddr" form, one
-// VGPR of address instead of a 64-bit pair per access
-__device__ __forceinline__ const float2 *at(const float2 *base, uint32_t byte_off)
-{
-    return reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-__device__ __forceinline__ float2 *at(float2 *base, uint32_t byte_off)
-{
-    return reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off);
-}
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-    return float2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
-}
-
-// cos / sin of 2*pi*j/32, j < 16
-__device__ constexpr float kC32[16] = { 1.0f,
-                                        0.98078528040323044913f,
-                                        0.92387953251128675613f,
-                                        0.83146961230254523708f,
-                                        0.70710678118654752440f,
-                                        0.55557023301960222474f,
-                                        0.38268343236508977173f,
-                                        0.19509032201612826785f,
-                                        0.0f,
-                                        -0.19509032201612826785f,
-                                        -0.38268343236508977173f,
-                                        -0.55557023301960222474f,
-                                        -0.70710678118654752440f,
-                                        -0.83146961230254523708f,
-                                        -0.92387953251128675613f,
-                                        -0.98078528040323044913f };
-__device__ constexpr float kS32[16] = { 0.0f,
-                                        0.19509032201612826785f,
-                                        0.38268343236508977173f,
-                                        0.55557023301960222474f,
-                                        0.70710678118654752440f,
-                                        0.83146961230254523708f,
-                                        0.92387953251128675613f,
-                                        0.98078528040323044913f,
-                                        1.0f,
-                                        0.98078528040323044913f,
-                                        0.92387953251128675613f,
-                                        0.83146961230254523708f,
-                                        0.70710678118654752440f,
-                                        0.55557023301960222474f,
-                                        0.38268343236508977173f,
-                                        0.19509032201612826785f };
-
-// Five radix-2 DIF stages on 32 registers: x[k] is the element at base + k*stride.  Stage s pairs
-// (k, k + h), h = 16 >> s.  The lower output owes the twiddle W_{2H}^(pos mod H) (fft.h:286 applies
-// the same factor on the DIT side); it factors into the thread's w[s] (absent when TW is false) and
-// the compile-time constant W_32^((k mod h) << s).  After full unrolling e is a literal.
-// `wsrc` is the table W_1024^j (LDS or global) and `u` the thread's index: stage s fetches its
-// thread twiddle W_1024^(u << s) when the stage starts, so it does not occupy registers earlier.
-template <bool REV, bool TW> __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, uint32_t u)
-{
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int h = 16 >> s;
-        float2 ws = float2{ 1.0f, 0.0f };
-        if constexpr (TW)
-            ws = wsrc[u << s];
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            if ((k & h) != 0)
-                continue;
-            const float2 a = x[k], b = x[k + h];
-            x[k] = a + b;
-            float2 d = a - b;
-            const int e = (k & (h - 1)) << s; // W_32 exponent, 0..15
-            if (e == 8) {
-                d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x }; // -i / +i by swap and negate
-            } else if (e != 0) {
-                const float cr = kC32[e], ci = REV ? kS32[e] : -kS32[e];
-                d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
-            }
-            if constexpr (TW)
-                d = cmul(d, ws);
-            x[k + h] = d;
-        }
-    }
-}
-
-__device__ __forceinline__ uint32_t brev5(uint32_t v) { return __brev(v) >> 27; }
+using namespace fft32;
 
 constexpr int kTile = 16;     // sequences per workgroup
 constexpr int kThreads = 512; // 16 sequences x 32 threads

@@ -1,0 +1,179 @@
+// fft_big.hip -- batched N = 8192 / 16384 / 32768 complex f32 FFT with radix-2 butterfly stages
+// (sdsp::fft_radix2, fft.h:258-299) in ONE pass over HBM, for gfx950.
+//
+// These sizes are too large for the register-pass family's "whole tile in LDS" scheme to keep more
+// than one workgroup on a CU (N = 16384 is 128 KiB of complex f32), so nothing overlapped the load and
+// store phases there (44-51 % of HBM peak; this kernel: 75 % at 8192, 65 % at 16384, 42 % at 32768 --
+// where the previous path was the two-pass four-step).  Measured with the butterflies and the exchanges
+// compiled out, the bare load/store pattern of this kernel runs at 97-103 % of 8 TB/s: what is left is the
+// un-overlapped on-chip work between a wave's last load and its first store.  Here the transform lives in REGISTERS, 32 points per
+// thread (N/32 threads per transform, one transform per workgroup), and LDS is only the exchange medium
+// between register passes -- moved one plane (real, then imaginary) at a time, so a transform needs
+// 4*N bytes of LDS and TWO workgroups of N = 16384 (four of N = 8192) share a CU:
+//
+//   load     x[k] = data[t + T*k]            T = N/32; a wave reads 512 contiguous bytes per instruction
+//   pass A   five DIF stages, strides N/2 .. N/32      thread twiddles W_N^(t << s)
+//   exchange position k*M + t  ->  blk*M + v + (j << R)            M = N/32, R = log2(N) - 10
+//   pass B   five DIF stages inside the 32 blocks of M points     thread twiddles W_N^(32 v << s)
+//   exchange position blk*M + v + (j << R)  ->  32*w + i,  w = bit_reverse(t)
+//   pass C   the last R stages (3, 4 or 5) on 32 contiguous positions, constants only
+//   store    X[t + T*bit_reverse5(i)] = x[i]           coalesced: the bit reversal (fft.h:269-273) is
+//                                                      folded into pass C's choice of w
+//
+// Stage twiddles are fetched from the plan's HBM-resident row W_N^j (L2 resident) when the stage starts
+// and combined with compile-time W_32 constants (fft32.h).  LDS positions are XOR-swizzled
+// (sw() below) so that all three access patterns are bank-conflict free.
+#include <hip/hip_runtime.h>
+
+#include "fft32.h"
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+using namespace fft32;
+
+// Bank = low 6 bits of the position.  Pattern B (64 lanes = 2^(6-R) blocks x 2^R consecutive v) needs
+// the low block bits p[5+R .. 10] in bank bits R .. 5; pattern C (lanes = the top six bits of w, i.e.
+// p[R+4] and the five block bits) needs p[R+4], p[5+R .. L-1] to reach all six bank bits: the remaining
+// p[11 .. L-1] go to bank bits 0 .. R-2 and p[R+4] to bank bit R-1.  The XOR term depends only on
+// p >> (R+4), so 16 consecutive positions stay consecutive.
+template <int L> __device__ __forceinline__ uint32_t sw(uint32_t p)
+{
+    constexpr int R = L - 10;
+    return p ^ ((((p >> (5 + R)) & ((1u << (6 - R)) - 1)) << R) | ((p >> 11) & ((1u << (R - 1)) - 1)) | (((p >> (R + 4)) & 1u) << (R - 1)));
+}
+
+template <int L, bool REV, bool NT>
+__global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                                       float scale)
+{
+    constexpr int R = L - 10;
+    constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft_big_smem); // N floats
+
+    const uint32_t t = threadIdx.x;
+    float2 *base = data + static_cast<uint64_t>(blockIdx.x) * N;
+    const uint32_t toff = t * 8u;
+
+    float2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = NT ? nt_load(at(base + T * k, toff)) : *at(base + T * k, toff);
+
+    fft32_dif<REV, true>(x, tw, t);
+
+    const uint32_t blk = t >> R, v = t & ((1u << R) - 1);
+    const uint32_t pb = blk * M + v; // pass-B position of register j: pb + (j << R)
+    // ---- exchange A -> B, one plane at a time
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint32_t ta = t, tb = pb;
+        asm volatile("" : "+v"(ta), "+v"(tb)); // keep the 64 swizzled addresses out of long-lived registers
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            plane[sw<L>(k * M + ta)] = half ? x[k].y : x[k].x;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const float f = plane[sw<L>(tb + (j << R))];
+            if (half)
+                x[j].y = f;
+            else
+                x[j].x = f;
+        }
+        __syncthreads();
+    }
+
+    fft32_dif<REV, true>(x, tw, 32u * v);
+
+    // ---- exchange B -> C
+    const uint32_t w = __brev(t) >> (32 - (L - 5));
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint32_t tb = pb, tc = 32u * w;
+        asm volatile("" : "+v"(tb), "+v"(tc));
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+            plane[sw<L>(tb + (j << R))] = half ? x[j].y : x[j].x;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const float f = plane[sw<L>(tc + i)];
+            if (half)
+                x[i].y = f;
+            else
+                x[i].x = f;
+        }
+        if (half == 0)
+            __syncthreads();
+    }
+
+    fft32_dif<REV, false, 5 - R>(x, tw, 0);
+
+    // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        float2 o = x[i];
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            o.x *= scale;
+            o.y *= scale;
+        }
+        float2 *dst = at(base + T * (int)(__brev((uint32_t)i) >> 27), toff);
+        if constexpr (NT)
+            nt_store(dst, o);
+        else
+            *dst = o;
+    }
+}
+
+template <int L, bool REV, bool NT> int launch_l(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr size_t lds = sizeof(float) << L;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT>;
+    if constexpr (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
+    if (a.batch > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((uint32_t)a.batch), dim3((1u << L) / 32), lds, s, reinterpret_cast<float2 *>(a.data),
+                       reinterpret_cast<const float2 *>(a.tw), a.scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_big launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
+template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
+{
+    if (a.nontemporal)
+        return a.reverse ? launch_l<L, true, true>(a, s) : launch_l<L, false, true>(a, s);
+    return a.reverse ? launch_l<L, true, false>(a, s) : launch_l<L, false, false>(a, s);
+}
+} // namespace
+
+bool fft_big_supports(uint32_t n, int radix)
+{
+    return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
+}
+
+int launch_fft_big_f32(const fft_reg_args &a, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (a.n) {
+    case 8192: return launch_dir<13>(a, s);
+    case 16384: return launch_dir<14>(a, s);
+    case 32768: return launch_dir<15>(a, s);
+    default: break;
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the large single-pass kernels");
+}
+} // namespace sdsp_hip

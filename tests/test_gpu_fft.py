@@ -128,9 +128,12 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_reg_kernel")
+        big = radix == 2 and n >= 8192  # registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
+        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else
+                                             "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
         outs = []
-        for variant in (0, 1, 99) if (n, radix) != (4096, 2) else (2, 1, 99, 0):  # streaming / default policy / coverage kernel / tuned r2
+        # streaming / default policy / coverage kernel (/ tuned r2 or large-transform kernel)
+        for variant in (2, 1, 99, 0) if ((n, radix) == (4096, 2) or big) else (0, 1, 99):
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector
@@ -210,6 +213,41 @@ def test_four_step_large_transforms(sd, torch_cuda, oracle, n, radix, batch):
     if n <= (1 << 16):
         got64 = _run(sd, torch_cuda, x.astype(np.complex128), radix, sd.forward_fft, sd.F64)
         assert rel_max_err(got64, want) < _tol64(n)
+
+
+@pytest.mark.parametrize("n", [8192, 16384, 32768])
+@pytest.mark.parametrize("batch", [1, 5, 300])
+def test_large_single_pass_kernel(sd, torch_cuda, oracle, n, batch):
+    """csrc/fft_big.hip (N = 8192 / 16384 / 32768 radix 2, f32): against the oracle on a few transforms,
+    against the previous kernels (register family / four-step, variant 1) on all of them, forward and
+    reverse, plus the round trip."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n + batch)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        plan = sd.FftPlan(n, 2, T, sd.F32, max_batch=batch)
+        assert plan.info.kernel.decode() == "sdsp_fft_big_kernel" and plan.info.hbm_passes == 1
+        d = torch.from_numpy(x).cuda()
+        guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
+        plan.exec(d)
+        torch.cuda.synchronize()
+        got = d.cpu().numpy()
+        assert bool((guard == 7.0 + 3.0j).all())
+        pick = sorted({0, batch - 1, batch // 2})
+        want = oracle.fft(x[pick].astype(np.complex128), 2, rev)
+        assert rel_max_err(got[pick], want) < TOL32, rel_max_err(got[pick], want)
+        plan.set_variant(1)
+        d2 = torch.from_numpy(x).cuda()
+        plan.exec(d2)
+        torch.cuda.synchronize()
+        assert rel_max_err(got, d2.cpu().numpy().astype(np.complex128)) < TOL32
+    fwd = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch)
+    inv = sd.FftPlan(n, 2, sd.reverse_fft, sd.F32, max_batch=batch)
+    d = torch.from_numpy(x).cuda()
+    fwd.exec(d)
+    inv.exec(d)
+    torch.cuda.synchronize()
+    assert rel_max_err(d.cpu().numpy(), x) < TOL32
 
 
 def test_fft1m_chunking_and_two_stream_variants_agree(sd, torch_cuda, oracle):
