@@ -64,6 +64,39 @@ int upload_twiddles(const std::vector<double> &w, int precision, void **dev)
     return SDSP_HIP_OK;
 }
 
+// Thread-twiddle table of the tuned N = 4096 f32 kernels (fft4096.hip): the stage twiddles each thread needs,
+// taken from the row W_4096^j (same rounded values) and laid out [value][thread] so the kernel reads them
+// with coalesced loads.  radix 4: W^(r t), W^(4 r t) (r = 1..3, t < 256), then W^(16 r rr), W^(64 r rr)
+// (rr < 16); radix 2: W^(t << j) (j < 4), then W^((16 rr) << j).
+int upload_thread_twiddles_4096(const std::vector<double> &w, int radix, void **dev)
+{
+    std::vector<float> tab;
+    auto put = [&](uint32_t idx) {
+        tab.push_back((float)w[2 * idx]);
+        tab.push_back((float)w[2 * idx + 1]);
+    };
+    if (radix == 4) {
+        for (uint32_t mult : { 1u, 4u })
+            for (uint32_t r = 1; r < 4; r++)
+                for (uint32_t t = 0; t < 256; t++)
+                    put(mult * r * t);
+        for (uint32_t mult : { 16u, 64u })
+            for (uint32_t r = 1; r < 4; r++)
+                for (uint32_t rr = 0; rr < 16; rr++)
+                    put(mult * r * rr);
+    } else {
+        for (uint32_t j = 0; j < 4; j++)
+            for (uint32_t t = 0; t < 256; t++)
+                put(t << j);
+        for (uint32_t j = 0; j < 4; j++)
+            for (uint32_t rr = 0; rr < 16; rr++)
+                put((16 * rr) << j);
+    }
+    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
@@ -76,6 +109,7 @@ struct sdsp_hip_fft_plan {
     void *tw = nullptr;            // W_n (single pass) or W_N (four-step inter-pass twiddle)
     void *tw1 = nullptr;           // four-step: W_n1
     void *tw2 = nullptr;           // four-step: W_n2
+    void *twt = nullptr;           // tuned N = 4096 f32 kernels: thread-twiddle table
     uint32_t n1 = 0, n2 = 0;       // four-step split
     uint32_t cols = 1, pitch = 1;  // tile shape (single pass)
     uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
@@ -127,21 +161,22 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants()) {
         fft4096_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt;
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
         return launch_fft4096_r4_f32(a, p->variant, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->n == 4096 && p->radix == 2 &&
-        !p->real_mode) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (p->variant == 0 || p->variant == 3) && p->n == 4096 &&
+        p->radix == 2 && !p->real_mode) {
         fft4096_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt;
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
+        a.pair = p->variant == 3; // 3: two consecutive transforms per workgroup
         return launch_fft4096_r2_f32(a, stream);
     }
 
@@ -451,6 +486,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         make_twiddles(n, direction, w);
         rc = upload_twiddles(w, precision, &p->tw);
         p->twiddle_bytes = (uint64_t)n * esize(precision);
+        if (!rc && n == 4096 && precision == SDSP_HIP_F32)
+            rc = upload_thread_twiddles_4096(w, radix, &p->twt);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
@@ -533,6 +570,7 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->tw);
         (void)hipFree(p->tw1);
         (void)hipFree(p->tw2);
+        (void)hipFree(p->twt);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
         if (p->partner)
@@ -639,7 +677,7 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
     if (int rc = use_device(p->device))
         return rc;
     if (p->path == PATH_FFT4096 && p->variant == 0)
-        return launch_fft4096_conv_f32(data, p->tw, h, batch, stream);
+        return launch_fft4096_conv_f32(data, p->twt, h, batch, stream);
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode) {
         fft_reg_args a;
         a.data = data;

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t rev4bits(uint32_t v) // reverse the low 4 bi
 
 // PREFETCH: fetch transform i+1 into registers during passes B/C of transform i (costs 32 VGPRs).
 // WAVES: occupancy the register allocator must leave room for (waves per SIMD = workgroups per CU).
-template <bool REV, bool PREFETCH, int WAVES, bool NT>
+template <bool REV, int PREFETCH, int WAVES, bool NT, int CHUNK = 2>
 __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__restrict__ data,
                                                                   const float2 *__restrict__ tw,
                                                                   uint64_t batch, float scale)
@@ -164,12 +164,15 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     // same single row exp(-+2 pi i j / N) of the table)
     float2 wA1[3], wA2[3], wB1[3], wB2[3];
     const uint32_t rr = t & 15, b = t >> 4;
+    // `tw` is the plan's THREAD-TWIDDLE table (capi.hip: make_thread_twiddles), the same values as the
+    // row W_4096^j laid out [value][thread] so that these are coalesced loads: gathering them from the row
+    // (strides of 8..96 bytes per lane) cost about as many cache-line requests as the transform's data
 #pragma unroll
     for (int r = 1; r < 4; r++) {
-        wA1[r - 1] = tw[r * t];        // W_4096^(r t)
-        wA2[r - 1] = tw[4 * r * t];    // W_1024^(r t)
-        wB1[r - 1] = tw[16 * r * rr];  // W_256^(r rr)
-        wB2[r - 1] = tw[64 * r * rr];  // W_64^(r rr)
+        wA1[r - 1] = tw[(r - 1) * 256 + t];        // W_4096^(r t)
+        wA2[r - 1] = tw[(r + 2) * 256 + t];        // W_1024^(r t)  = W_4096^(4 r t)
+        wB1[r - 1] = tw[1536 + (r - 1) * 16 + rr]; // W_256^(r rr)  = W_4096^(16 r rr)
+        wB2[r - 1] = tw[1536 + (r + 2) * 16 + rr]; // W_64^(r rr)   = W_4096^(64 r rr)
     }
 
     // ---- LDS addressing (float2 units).  Loop-invariant address VECTORS are deliberately not kept
@@ -190,14 +193,26 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     const uint32_t c_x = (xc >> 1) & 7; // pair index i -> i ^ c_x
 
     float2 x[16], nx[PREFETCH ? 16 : 1];
-    uint64_t f = blockIdx.x;
+    // PREFETCH == 2 ("pair"): the workgroup owns transforms 2b and 2b+1 -- 64 contiguous KiB, the shape
+    // whose bare load/store pattern reaches HBM peak (fft_big.hip) -- loads both up front and runs them
+    // one after the other.
+    constexpr uint64_t kStep = PREFETCH == 2 ? 1 : 0;
+    uint64_t f = PREFETCH == 2 ? CHUNK * (uint64_t)blockIdx.x : blockIdx.x;
+    const uint64_t f_end = PREFETCH == 2 ? (f + CHUNK < batch ? f + CHUNK : batch) : batch;
     if (PREFETCH && f < batch) {
         const float2 *src = data + f * 4096 + t;
 #pragma unroll
         for (int k = 0; k < 16; k++)
             x[k] = gload<NT>(src + 256 * k);
+        if constexpr (PREFETCH == 2) {
+            if (f + 1 < batch) {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    nx[k] = gload<NT>(src + 4096 + 256 * k);
+            }
+        }
     }
-    for (; f < batch; f += gridDim.x) {
+    for (; f < f_end; f += (kStep ? kStep : gridDim.x)) {
         if constexpr (!PREFETCH) {
             const float2 *src = data + f * 4096 + t;
 #pragma unroll
@@ -216,8 +231,8 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
         __syncthreads();
 
         // prefetch the next transform; in flight during passes B and C
-        const uint64_t fn = f + gridDim.x;
-        if constexpr (PREFETCH) {
+        const uint64_t fn = f + (kStep ? kStep : gridDim.x);
+        if constexpr (PREFETCH == 1) {
             if (fn < batch) {
                 const float2 *src = data + fn * 4096 + t;
 #pragma unroll
@@ -257,7 +272,9 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
         // ---- store; register k = 4 d1 + d0 holds X[t + 256 * (4 d0 + d1)]: fft.h:351-355 folded
         float2 *dst = data + f * 4096 + t;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int j = 0; j < 16; j++) {
+            // CHUNK == 1 (variant 12): issue the stores in ascending address order
+            const int k = (PREFETCH == 0 && CHUNK == 1) ? 4 * (j & 3) + (j >> 2) : j;
             float2 v = x[k];
             if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
                 v.x *= scale;
@@ -270,6 +287,14 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                     x[k] = nx[k];
+            }
+        }
+        if constexpr (PREFETCH == 2 && CHUNK > 2) {
+            if (fn + 1 < f_end) { // keep one transform of loads in flight behind the one being computed
+                const float2 *src = data + (fn + 1) * 4096 + t;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    nx[k] = gload<NT>(src + 256 * k);
             }
         }
     }
@@ -346,11 +371,11 @@ __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restri
     float2 wA1[3], wA2[3], wB1[3], wB2[3];
     const uint32_t rr = t & 15, b = t >> 4;
 #pragma unroll
-    for (int r = 1; r < 4; r++) {
-        wA1[r - 1] = tw[r * t];
-        wA2[r - 1] = tw[4 * r * t];
-        wB1[r - 1] = tw[16 * r * rr];
-        wB2[r - 1] = tw[64 * r * rr];
+    for (int r = 1; r < 4; r++) { // thread-twiddle table, see sdsp_fft4096_r4_f32
+        wA1[r - 1] = tw[(r - 1) * 256 + t];
+        wA2[r - 1] = tw[(r + 2) * 256 + t];
+        wB1[r - 1] = tw[1536 + (r - 1) * 16 + rr];
+        wB2[r - 1] = tw[1536 + (r + 2) * 16 + rr];
     }
     lds_map mp;
     const uint32_t xb = rev4bits(b) << 1;
@@ -396,7 +421,9 @@ __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restri
 // tile and XOR swizzle (the bank analysis carries over to the bit-reversed block assignment), four
 // thread twiddles per pass instead of six.  The bit reversal (fft.h:269-273) is folded into the last
 // pass's assignment: thread t takes block bit_reverse8(t), whose outputs land at t + 256*bit_reverse4(k).
-template <bool REV, bool NT>
+// PAIR: the workgroup owns transforms 2b and 2b+1 (64 contiguous KiB), loads both up front and runs them
+// one after the other (see sdsp_fft4096_r4_f32).
+template <bool REV, bool NT, bool PAIR>
 __global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                               uint64_t batch, float scale)
 {
@@ -405,9 +432,9 @@ __global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict
     const uint32_t rr = t & 15, b = t >> 4;
     float2 wA[4], wB[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        wA[j] = tw[t << j];         // stage j of pass A: W_{8192 >> j ... } = W_4096^(t 2^j)
-        wB[j] = tw[(16 * rr) << j]; // pass B: W_4096^(16 rr 2^j)
+    for (int j = 0; j < 4; j++) { // thread-twiddle table (coalesced), see sdsp_fft4096_r4_f32
+        wA[j] = tw[j * 256 + t];         // stage j of pass A: W_4096^(t 2^j)
+        wB[j] = tw[1024 + j * 16 + rr];  // pass B: W_4096^(16 rr 2^j)
     }
     const uint32_t xb = rev4bits(b) << 1;
     const uint32_t b_base = 256 * b + (rr ^ (xb & 15));
@@ -419,12 +446,29 @@ __global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict
     const uint32_t c_base = 256 * (m >> 4) + 16 * ((m & 15) ^ (xc >> 4));
     const uint32_t c_x = (xc >> 1) & 7;
 
-    for (uint64_t f = blockIdx.x; f < batch; f += gridDim.x) {
-        float2 x[16];
+    float2 x[16], nx[PAIR ? 16 : 1];
+    uint64_t f = PAIR ? 2 * (uint64_t)blockIdx.x : blockIdx.x;
+    const uint64_t f_end = PAIR ? (f + 2 < batch ? f + 2 : batch) : batch;
+    if constexpr (PAIR) {
         const float2 *src = data + f * 4096 + t;
+        if (f < batch) {
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            x[k] = gload<NT>(src + 256 * k);
+            for (int k = 0; k < 16; k++)
+                x[k] = gload<NT>(src + 256 * k);
+        }
+        if (f + 1 < batch) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                nx[k] = gload<NT>(src + 4096 + 256 * k);
+        }
+    }
+    for (; f < f_end; f += (PAIR ? 1 : gridDim.x)) {
+        if constexpr (!PAIR) {
+            const float2 *src = data + f * 4096 + t;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                x[k] = gload<NT>(src + 256 * k);
+        }
         passes::r2_pass<REV, true, 0>::run(x, wA);
         {
             uint32_t ta = t;
@@ -468,6 +512,11 @@ __global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict
             }
             gstore<NT>(dst + 256 * (int)(__brev((uint32_t)k) >> 28), v);
         }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                x[k] = nx[k];
+        }
     }
 }
 
@@ -484,16 +533,16 @@ int cu_count()
     return cached;
 }
 
-template <bool PREFETCH, int WAVES, bool NT>
+template <int PREFETCH, int WAVES, bool NT, int CHUNK = 2>
 void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s)
 {
     float2 *d = reinterpret_cast<float2 *>(a.data);
     const float2 *w = reinterpret_cast<const float2 *>(a.tw);
     if (a.reverse)
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT>), dim3((uint32_t)grid), dim3(256), 0, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), 0, s, d,
                            w, a.batch, a.scale);
     else
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT>), dim3((uint32_t)grid), dim3(256), 0, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), 0, s, d,
                            w, a.batch, a.scale);
 }
 
@@ -506,14 +555,22 @@ struct variant_desc {
     bool nt;       // non-temporal global accesses
 };
 constexpr variant_desc kVariants[] = {
-    { false, 3, 0, true },  // 0 default: one workgroup per transform, 3 per CU (no spills), nt.
-                            //   measured 5.81 TB/s = 72.6 % of HBM peak (sweep, round 1)
+    { false, 3, 0, true },  // 0 default: one workgroup per transform, nt; 100 VGPRs -> 4 workgroups per CU.
+                            //   73.7 % of HBM peak (71.6 % before the thread-twiddle table made its twiddle loads coalesced)
     { false, 4, 0, true },  // 1 as 0 at 4 per CU: 20 B/lane of scratch cost 17 %
     { true, 3, 3, true },   // 2 persistent + register prefetch: 5.49 TB/s
     { true, 2, 2, true },   // 3
     { false, 3, 6, true },  // 4 persistent, no prefetch, 2x oversubscribed
     { false, 3, 0, false }, // 5 as 0 with the default cache policy
     { true, 3, 3, false },  // 6 as 2 with the default cache policy
+    { true, 3, 0, true },   // 7 "pair": one workgroup per TWO consecutive transforms (64 KiB -- the chunk whose bare
+                            //   load/store pattern reaches HBM peak), both loaded up front, run one after the other:
+                            //   74.0 % while twiddles were gathered (it halved that cost), 71.4 % with the table
+    { true, 2, 0, true },   // 8 as 7 at 2 per CU
+    { true, 3, 0, true },   // 9 four consecutive transforms per workgroup, one transform of loads kept in flight: 69.2 %
+    { true, 3, 0, true },   // 10 eight: 67.4 %
+    { true, 4, 0, true },   // 11 as 7 at 4 per CU
+    { false, 3, 0, true },  // 12 as 0 with the stores issued in ascending address order
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -527,10 +584,16 @@ int launch_fft4096_r2_f32(const fft4096_args &a, void *stream)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float2 *d = reinterpret_cast<float2 *>(a.data);
     const float2 *w = reinterpret_cast<const float2 *>(a.tw);
-    if (a.reverse)
-        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<true, true>), dim3((uint32_t)a.batch), dim3(256), 0, s, d, w, a.batch, a.scale);
+    const dim3 pair_grid((uint32_t)((a.batch + 1) / 2)), grid((uint32_t)a.batch);
+    if (a.pair) {
+        if (a.reverse)
+            hipLaunchKernelGGL((sdsp_fft4096_r2_f32<true, true, true>), pair_grid, dim3(256), 0, s, d, w, a.batch, a.scale);
+        else
+            hipLaunchKernelGGL((sdsp_fft4096_r2_f32<false, true, true>), pair_grid, dim3(256), 0, s, d, w, a.batch, a.scale);
+    } else if (a.reverse)
+        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<true, true, false>), grid, dim3(256), 0, s, d, w, a.batch, a.scale);
     else
-        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<false, true>), dim3((uint32_t)a.batch), dim3(256), 0, s, d, w, a.batch, a.scale);
+        hipLaunchKernelGGL((sdsp_fft4096_r2_f32<false, true, false>), grid, dim3(256), 0, s, d, w, a.batch, a.scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft4096 r2 launch: ") + hipGetErrorString(e));
@@ -575,13 +638,19 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
-    case 0: launch_variant<false, 3, true>(a, grid, s); break;
-    case 1: launch_variant<false, 4, true>(a, grid, s); break;
-    case 2: launch_variant<true, 3, true>(a, grid, s); break;
-    case 3: launch_variant<true, 2, true>(a, grid, s); break;
-    case 4: launch_variant<false, 3, true>(a, grid, s); break;
-    case 5: launch_variant<false, 3, false>(a, grid, s); break;
-    default: launch_variant<true, 3, false>(a, grid, s); break;
+    case 0: launch_variant<0, 3, true>(a, grid, s); break;
+    case 1: launch_variant<0, 4, true>(a, grid, s); break;
+    case 2: launch_variant<1, 3, true>(a, grid, s); break;
+    case 3: launch_variant<1, 2, true>(a, grid, s); break;
+    case 4: launch_variant<0, 3, true>(a, grid, s); break;
+    case 5: launch_variant<0, 3, false>(a, grid, s); break;
+    case 6: launch_variant<1, 3, false>(a, grid, s); break;
+    case 7: launch_variant<2, 3, true>(a, (a.batch + 1) / 2, s); break;
+    case 8: launch_variant<2, 2, true>(a, (a.batch + 1) / 2, s); break;
+    case 9: launch_variant<2, 3, true, 4>(a, (a.batch + 3) / 4, s); break;
+    case 10: launch_variant<2, 3, true, 8>(a, (a.batch + 7) / 8, s); break;
+    case 11: launch_variant<2, 4, true, 2>(a, (a.batch + 1) / 2, s); break;
+    default: launch_variant<0, 3, true, 1>(a, grid, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

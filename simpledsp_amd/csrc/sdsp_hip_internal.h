@@ -55,16 +55,17 @@ size_t fft_tile_max_lds_bytes();
 // fast path: batched n = 4096, radix 4, f32 (BASELINE config 2 / 5)
 struct fft4096_args {
     void *data;
-    const void *tw; // W_4096^j f32 complex
+    const void *tw; // the plan's thread-twiddle table (make_thread_twiddles_4096), f32 complex
     uint64_t batch;
     float scale;
     int reverse;
+    int pair = 0; // radix-2 sibling: two consecutive transforms per workgroup (measured slower: 67.7 vs 76.7 %)
 };
 int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
 const char *fft4096_kernel_name(int variant);
 int fft4096_num_variants();
 int launch_fft4096_r2_f32(const fft4096_args &a, void *stream); // tuned radix-2 sibling
-// fused y = IFFT(FFT(x) .* h), n = 4096, f32; tw = FORWARD twiddle row
+// fused y = IFFT(FFT(x) .* h), n = 4096, f32; tw = FORWARD thread-twiddle table
 int launch_fft4096_conv_f32(void *data, const void *tw, const void *h, uint64_t batch, void *stream);
 // data[b][i] *= h[i] (generic three-launch convolution path)
 int launch_pointwise_mul(int precision, void *data, const void *h, uint32_t n, uint64_t batch, void *stream);

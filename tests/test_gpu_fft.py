@@ -133,7 +133,7 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
                                              "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
         outs = []
         # streaming / default policy / coverage kernel (/ tuned r2 or large-transform kernel)
-        for variant in (2, 1, 99, 0) if ((n, radix) == (4096, 2) or big) else (0, 1, 99):
+        for variant in ((2, 1, 99, 0, 3) if (n, radix) == (4096, 2) else (2, 1, 99, 0) if big else (0, 1, 99)):
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector
@@ -178,7 +178,7 @@ def test_fft4096_ragged_batches_all_variants(sd, torch_cuda, oracle, batch):
     for T, ref in ((sd.forward_fft, want), (sd.reverse_fft, want_rev)):
         plan = sd.FftPlan(4096, 4, T, sd.F32, max_batch=batch)
         assert plan.info.kernel.decode().startswith("sdsp_fft4096_r4_f32")
-        for variant in range(7):
+        for variant in range(13):  # 7..11: two consecutive transforms per workgroup (ragged: odd batches)
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
