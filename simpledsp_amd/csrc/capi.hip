@@ -97,6 +97,34 @@ int upload_thread_twiddles_4096(const std::vector<double> &w, int radix, void **
     return SDSP_HIP_OK;
 }
 
+// Thread-twiddle table of the register-pass family (fft_reg.hip), f32: for every pass I that has thread
+// twiddles (point stride S = N >> 4(I+1) > 1) and every thread t < N/16 of a transform (r = t mod S,
+// unit = r * 16^I): six slots -- radix 2: W^(unit << v), v < 4; radix 4: W^(unit q), W^(4 unit q), q = 1..3.
+int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int radix, void **dev)
+{
+    const uint32_t log2n = sdsp_hip_log2(n), T = n / 16, P = (log2n + 3) / 4;
+    std::vector<float> tab((size_t)6 * P * T * 2, 0.0f);
+    for (uint32_t I = 0; I + 1 < P; I++) {
+        const uint32_t S = n >> (4 * (I + 1));
+        for (uint32_t t = 0; t < T; t++) {
+            const uint32_t unit = (t % S) << (4 * I);
+            for (uint32_t v = 0; v < 6; v++) {
+                uint32_t idx;
+                if (radix == 2)
+                    idx = v < 4 ? unit << v : 0;
+                else
+                    idx = v < 3 ? unit * (v + 1) : 4 * unit * (v - 2);
+                const size_t o = ((size_t)(6 * I + v) * T + t) * 2;
+                tab[o] = (float)w[2 * (size_t)idx];
+                tab[o + 1] = (float)w[2 * (size_t)idx + 1];
+            }
+        }
+    }
+    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
@@ -110,6 +138,7 @@ struct sdsp_hip_fft_plan {
     void *tw1 = nullptr;           // four-step: W_n1
     void *tw2 = nullptr;           // four-step: W_n2
     void *twt = nullptr;           // tuned N = 4096 f32 kernels: thread-twiddle table
+    void *twt_reg = nullptr;       // register-pass family (f32): thread-twiddle table
     uint32_t n1 = 0, n2 = 0;       // four-step split
     uint32_t cols = 1, pitch = 1;  // tile shape (single pass)
     uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
@@ -212,7 +241,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant < 3) {
         fft_reg_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt_reg;
         a.n = p->n;
         a.radix = p->radix;
         a.batch = batch;
@@ -488,6 +517,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->twiddle_bytes = (uint64_t)n * esize(precision);
         if (!rc && n == 4096 && precision == SDSP_HIP_F32)
             rc = upload_thread_twiddles_4096(w, radix, &p->twt);
+        if (!rc && precision == SDSP_HIP_F32 && fft_reg_supports(n, radix))
+            rc = upload_thread_twiddles_reg(w, n, radix, &p->twt_reg);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
@@ -571,6 +602,7 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->tw1);
         (void)hipFree(p->tw2);
         (void)hipFree(p->twt);
+        (void)hipFree(p->twt_reg);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
         if (p->partner)
@@ -681,7 +713,7 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode) {
         fft_reg_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt_reg;
         a.n = p->n;
         a.radix = p->radix;
         a.batch = batch;

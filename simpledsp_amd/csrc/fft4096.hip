@@ -571,6 +571,7 @@ constexpr variant_desc kVariants[] = {
     { true, 3, 0, true },   // 10 eight: 67.4 %
     { true, 4, 0, true },   // 11 as 7 at 4 per CU
     { false, 3, 0, true },  // 12 as 0 with the stores issued in ascending address order
+    { false, 5, 0, true },  // 13 as 0 squeezed to 96 VGPRs for 5 workgroups per CU: 24 B/lane of scratch, 67.7 %
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -650,7 +651,8 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
     case 9: launch_variant<2, 3, true, 4>(a, (a.batch + 3) / 4, s); break;
     case 10: launch_variant<2, 3, true, 8>(a, (a.batch + 7) / 8, s); break;
     case 11: launch_variant<2, 4, true, 2>(a, (a.batch + 1) / 2, s); break;
-    default: launch_variant<0, 3, true, 1>(a, grid, s); break;
+    case 12: launch_variant<0, 3, true, 1>(a, grid, s); break;
+    default: launch_variant<0, 5, true>(a, grid, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -169,8 +169,15 @@ template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 }
 } // namespace
 
+// Radix-4 plans of N = 16384 run here too: a radix-4 DIF stage (fft.h:311-349) is two fused radix-2 DIF
+// stages (the inner twiddle is -+i), so the 5 + 5 + 4 radix-2 stages of this kernel are the same dataflow as
+// the reference's seven radix-4 stages run unfused; the natural-order result is the same DFT to rounding
+// (tests hold it to the same 1e-6 against the oracle's radix-4 algorithm).  The register-pass family's
+// genuine two-stage radix-4 passes remain as variants 1 / 2 of such plans.
 bool fft_big_supports(uint32_t n, int radix)
 {
+    if (radix == 4)
+        return n == 16384;
     return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
 }
 

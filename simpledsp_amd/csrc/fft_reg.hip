@@ -82,6 +82,10 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
                                                                              const float2 *__restrict__ tw2,
                                                                              uint64_t batch, float scale)
 {
+    // `tw` is the plan's THREAD-TWIDDLE table (capi.hip: upload_thread_twiddles_reg): for pass I and value
+    // slot v, entry [(6 I + v) * T + t] is the twiddle thread t of a transform needs -- the same rounded
+    // values as the row W_N^j, but read with coalesced loads instead of gathers at strides of 8..96 B per lane
+    // (which cost about as many cache-line requests as the data itself; see fft4096.hip).
     constexpr int N = 1 << LOG2N;
     constexpr int kPoints = points_for(LOG2N);
     constexpr int THREADS = kPoints / 16;
@@ -166,9 +170,10 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
         for (int k = 0; k < 16; k++)
             x[k] = lds[slot(p0 + S * k)];
         constexpr bool TW = S > 1;          // r == 0 in the stride-1 pass: all thread twiddles are 1
-        const uint32_t unit = r << (4 * I); // r * 16^I: W_N^(unit * m) are this thread's twiddles
-        auto twl = [&](uint32_t idx) {
-            float2 w = tw[idx];
+        // slot v of pass I: radix 2: W_N^(unit << v), v < 4; radix 4: W_N^(unit (v+1)), v < 3, then
+        // W_N^(4 unit (v-2)), v = 3..5; unit = r * 16^I
+        auto twl = [&](uint32_t v) {
+            float2 w = tw[(6 * I + v) * T + t];
             if constexpr (CONJ)
                 w.y = -w.y;
             return w;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
             if constexpr (TW) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    w[j] = twl(unit << j);
+                    w[j] = twl(j);
             }
             r2_pass<RV, TW, is_last ? 4 - LAST : 0>::run(x, w);
         } else {
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
             if constexpr (TW) {
 #pragma unroll
                 for (int q = 1; q < 4; q++) {
-                    w1[q - 1] = twl(unit * q);
-                    w2[q - 1] = twl(unit * 4 * q);
+                    w1[q - 1] = twl(q - 1);
+                    w2[q - 1] = twl(q + 2);
                 }
             }
             r4_pass<RV, TW, !(is_last && LAST == 2)>(x, w1, w2);

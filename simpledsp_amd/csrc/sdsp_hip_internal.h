@@ -73,7 +73,7 @@ int launch_pointwise_mul(int precision, void *data, const void *h, uint32_t n, u
 // fast path for every other batched f32 size 16 .. 4096, radix 2 or 4 (register-pass family)
 struct fft_reg_args {
     void *data;
-    const void *tw; // W_n^j
+    const void *tw; // fft_reg.hip (f32): the plan's thread-twiddle table; fft_reg64 / fft_big: the row W_n^j
     uint32_t n;
     int radix;
     uint64_t batch;

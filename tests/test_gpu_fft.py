@@ -128,7 +128,7 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        big = radix == 2 and n >= 8192  # registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
+        big = n >= 8192  # registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there (radix-4 16384 too)
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else
                                              "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
         outs = []
@@ -178,7 +178,7 @@ def test_fft4096_ragged_batches_all_variants(sd, torch_cuda, oracle, batch):
     for T, ref in ((sd.forward_fft, want), (sd.reverse_fft, want_rev)):
         plan = sd.FftPlan(4096, 4, T, sd.F32, max_batch=batch)
         assert plan.info.kernel.decode().startswith("sdsp_fft4096_r4_f32")
-        for variant in range(13):  # 7..11: two consecutive transforms per workgroup (ragged: odd batches)
+        for variant in range(14):  # 7..13: two consecutive transforms per workgroup (ragged: odd batches)
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             plan.exec(d)

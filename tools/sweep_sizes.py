@@ -18,11 +18,11 @@ for n in sizes:
         x = buf.view(batch, n)
         fwd = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=min(batch, 64))
         rev = sd.FftPlan(n, radix, sd.reverse_fft, sd.F32, max_batch=min(batch, 64))
-        for _ in range(2):
+        for _ in range(12):  # steady state: the first ~20 launches after idle run slower (clock ramp)
             fwd.exec(x); rev.exec(x)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 4
+        reps = 10
         e0.record()
         for _ in range(reps):
             fwd.exec(x); rev.exec(x)
