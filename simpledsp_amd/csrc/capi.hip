@@ -125,6 +125,25 @@ int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int rad
     return SDSP_HIP_OK;
 }
 
+// Thread-twiddle table of fft_big.hip: [pass (A, B)][stage s < 5][thread t < N/32] = W^(t << s) for pass A,
+// W^((32 v) << s), v = t mod (N/1024), for pass B.
+int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **dev)
+{
+    const uint32_t T = n / 32, vmask = n / 1024 - 1;
+    std::vector<float> tab((size_t)10 * T * 2);
+    for (uint32_t pass = 0; pass < 2; pass++)
+        for (uint32_t s = 0; s < 5; s++)
+            for (uint32_t t = 0; t < T; t++) {
+                const uint32_t idx = (pass == 0 ? t : 32 * (t & vmask)) << s;
+                const size_t o = ((size_t)(pass * 5 + s) * T + t) * 2;
+                tab[o] = (float)w[2 * (size_t)idx];
+                tab[o + 1] = (float)w[2 * (size_t)idx + 1];
+            }
+    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
@@ -139,6 +158,7 @@ struct sdsp_hip_fft_plan {
     void *tw2 = nullptr;           // four-step: W_n2
     void *twt = nullptr;           // tuned N = 4096 f32 kernels: thread-twiddle table
     void *twt_reg = nullptr;       // register-pass family (f32): thread-twiddle table
+    void *twt_big = nullptr;       // fft_big.hip: thread-twiddle table
     uint32_t n1 = 0, n2 = 0;       // four-step split
     uint32_t cols = 1, pitch = 1;  // tile shape (single pass)
     uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
@@ -214,7 +234,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         !p->real_mode && fft_big_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt_big;
         a.n = p->n;
         a.radix = p->radix;
         a.batch = batch;
@@ -519,6 +539,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
             rc = upload_thread_twiddles_4096(w, radix, &p->twt);
         if (!rc && precision == SDSP_HIP_F32 && fft_reg_supports(n, radix))
             rc = upload_thread_twiddles_reg(w, n, radix, &p->twt_reg);
+        if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
+            rc = upload_thread_twiddles_big(w, n, &p->twt_big);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
@@ -534,6 +556,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->n2 = n / p->n1;
         make_twiddles(n, direction, w);
         rc = upload_twiddles(w, precision, &p->tw);
+        if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
+            rc = upload_thread_twiddles_big(w, n, &p->twt_big);
         if (!rc) {
             make_twiddles(p->n1, direction, w);
             rc = upload_twiddles(w, precision, &p->tw1);
@@ -603,6 +627,7 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->tw2);
         (void)hipFree(p->twt);
         (void)hipFree(p->twt_reg);
+        (void)hipFree(p->twt_big);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
         if (p->partner)

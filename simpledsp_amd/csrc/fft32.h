@@ -80,7 +80,9 @@ __device__ constexpr float kS32[16] = { 0.0f,
 // `wsrc` is the table W_1024^j (LDS or global) and `u` the thread's index: stage s fetches its
 // thread twiddle W_1024^(u << s) when the stage starts, so it does not occupy registers earlier.
 // S0 > 0 skips the first S0 stages: the 32 registers then hold 2^S0 independent groups of 32 >> S0 points.
-template <bool REV, bool TW, int S0 = 0>
+// TABLE: wsrc points at the thread's column of a [stage][thread] thread-twiddle table with row pitch u, so
+// stage s reads wsrc[s * u] (coalesced across lanes) instead of gathering wsrc[u << s] from the row W^j.
+template <bool REV, bool TW, int S0 = 0, bool TABLE = false>
 __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, uint32_t u)
 {
 #pragma unroll
@@ -88,7 +90,7 @@ __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, u
         const int h = 16 >> s;
         float2 ws = float2{ 1.0f, 0.0f };
         if constexpr (TW)
-            ws = wsrc[u << s];
+            ws = TABLE ? wsrc[s * u] : wsrc[u << s];
 #pragma unroll
         for (int k = 0; k < 32; k++) {
             if ((k & h) != 0)

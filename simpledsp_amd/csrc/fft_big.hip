@@ -3,7 +3,7 @@
 //
 // These sizes are too large for the register-pass family's "whole tile in LDS" scheme to keep more
 // than one workgroup on a CU (N = 16384 is 128 KiB of complex f32), so nothing overlapped the load and
-// store phases there (44-51 % of HBM peak; this kernel: 75 % at 8192, 65 % at 16384, 42 % at 32768 --
+// store phases there (44-51 % of HBM peak; this kernel: 67 % at 8192, 60 % at 16384, 41 % at 32768 --
 // where the previous path was the two-pass four-step).  Measured with the butterflies and the exchanges
 // compiled out, the bare load/store pattern of this kernel runs at 97-103 % of 8 TB/s: what is left is the
 // un-overlapped on-chip work between a wave's last load and its first store.  Here the transform lives in REGISTERS, 32 points per
@@ -20,8 +20,9 @@
 //   store    X[t + T*bit_reverse5(i)] = x[i]           coalesced: the bit reversal (fft.h:269-273) is
 //                                                      folded into pass C's choice of w
 //
-// Stage twiddles are fetched from the plan's HBM-resident row W_N^j (L2 resident) when the stage starts
-// and combined with compile-time W_32 constants (fft32.h).  LDS positions are XOR-swizzled
+// Stage twiddles come from a per-plan thread-twiddle table ([pass][stage][thread]: the values W_N^(t << s)
+// and W_N^(32 v << s) of the row W_N^j, laid out for coalesced loads) when the stage starts and are combined
+// with compile-time W_32 constants (fft32.h).  LDS positions are XOR-swizzled
 // (sw() below) so that all three access patterns are bank-conflict free.
 #include <hip/hip_runtime.h>
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
             x[k] = NT ? nt_load(at(base + T * k, toff)) : *at(base + T * k, toff);
     }
 
-    fft32_dif<REV, true>(x, tw, t);
+    fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
 
     const uint32_t blk = t >> R, v = t & ((1u << R) - 1);
     const uint32_t pb = blk * M + v; // pass-B position of register j: pb + (j << R)
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
         __syncthreads();
     }
 
-    fft32_dif<REV, true>(x, tw, 32u * v);
+    fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T);
 
     // ---- exchange B -> C
     const uint32_t w = __brev(t) >> (32 - (L - 5));
