@@ -266,8 +266,13 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
                 x[2 * i + 1] = float2{ v.z, v.w };
             }
         }
-        __syncthreads(); // every read of this transform is done: the tile may be overwritten
+        // every read of this transform is done: the tile may be overwritten -- by the NEXT transform of this
+        // workgroup, so a workgroup on its last (usually only) transform skips the barrier (wave-uniform test)
+        if (f + (kStep ? kStep : gridDim.x) < f_end || CHUNK == 1)
+            __syncthreads();
         two_stages<REV, false, false>(x, wA1, wA2);
+        if constexpr (CHUNK == 3)
+            __syncthreads();
 
         // ---- store; register k = 4 d1 + d0 holds X[t + 256 * (4 d0 + d1)]: fft.h:351-355 folded
         float2 *dst = data + f * 4096 + t;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void sdsp_fft4096_r2_f32(float2 *__restrict
                 x[2 * i + 1] = float2{ v.z, v.w };
             }
         }
-        __syncthreads();
+        __syncthreads(); // also keeps the four waves' stores together: without it 77.3 % -> 73.7 %
         passes::r2_pass<REV, false, 0>::run(x, wA);
         float2 *dst = data + f * 4096 + t;
 #pragma unroll
@@ -556,7 +561,8 @@ struct variant_desc {
 };
 constexpr variant_desc kVariants[] = {
     { false, 3, 0, true },  // 0 default: one workgroup per transform, nt; 100 VGPRs -> 4 workgroups per CU.
-                            //   73.7 % of HBM peak (71.6 % before the thread-twiddle table made its twiddle loads coalesced)
+                            //   74.9 % of HBM peak (71.6 % before the thread-twiddle table made its twiddle loads coalesced,
+                            //   74.2 % with a barrier after the last LDS read that only a looping workgroup needs)
     { false, 4, 0, true },  // 1 as 0 at 4 per CU: 20 B/lane of scratch cost 17 %
     { true, 3, 3, true },   // 2 persistent + register prefetch: 5.49 TB/s
     { true, 2, 2, true },   // 3
@@ -570,8 +576,10 @@ constexpr variant_desc kVariants[] = {
     { true, 3, 0, true },   // 9 four consecutive transforms per workgroup, one transform of loads kept in flight: 69.2 %
     { true, 3, 0, true },   // 10 eight: 67.4 %
     { true, 4, 0, true },   // 11 as 7 at 4 per CU
-    { false, 3, 0, true },  // 12 as 0 with the stores issued in ascending address order
-    { false, 5, 0, true },  // 13 as 0 squeezed to 96 VGPRs for 5 workgroups per CU: 24 B/lane of scratch, 67.7 %
+    { false, 3, 0, true },  // 12 as 0 with the stores issued in ascending address order and the (redundant) barrier after
+                            //    the last LDS read of a workgroup's only transform kept: 74.1 % where 0 gives 74.9 %
+    { false, 3, 0, true },  // 13 as 0 with a barrier right before the stores (keeps the four waves' stores together): 74.8 %
+                            //    (squeezing 0 to 96 VGPRs for a fifth workgroup per CU cost 24 B/lane of scratch: 67.7 %)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -652,7 +660,7 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
     case 10: launch_variant<2, 3, true, 8>(a, (a.batch + 7) / 8, s); break;
     case 11: launch_variant<2, 4, true, 2>(a, (a.batch + 1) / 2, s); break;
     case 12: launch_variant<0, 3, true, 1>(a, grid, s); break;
-    default: launch_variant<0, 5, true>(a, grid, s); break;
+    default: launch_variant<0, 3, true, 3>(a, grid, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
