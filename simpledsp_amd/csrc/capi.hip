@@ -97,13 +97,13 @@ int upload_thread_twiddles_4096(const std::vector<double> &w, int radix, void **
     return SDSP_HIP_OK;
 }
 
-// Thread-twiddle table of the register-pass family (fft_reg.hip), f32: for every pass I that has thread
+// Thread-twiddle table of the register-pass families (fft_reg.hip, fft_reg64.hip): for every pass I that has thread
 // twiddles (point stride S = N >> 4(I+1) > 1) and every thread t < N/16 of a transform (r = t mod S,
 // unit = r * 16^I): six slots -- radix 2: W^(unit << v), v < 4; radix 4: W^(unit q), W^(4 unit q), q = 1..3.
-int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int radix, void **dev)
+int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int radix, int precision, void **dev)
 {
     const uint32_t log2n = sdsp_hip_log2(n), T = n / 16, P = (log2n + 3) / 4;
-    std::vector<float> tab((size_t)6 * P * T * 2, 0.0f);
+    std::vector<double> tab((size_t)6 * P * T * 2, 0.0);
     for (uint32_t I = 0; I + 1 < P; I++) {
         const uint32_t S = n >> (4 * (I + 1));
         for (uint32_t t = 0; t < T; t++) {
@@ -115,14 +115,12 @@ int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int rad
                 else
                     idx = v < 3 ? unit * (v + 1) : 4 * unit * (v - 2);
                 const size_t o = ((size_t)(6 * I + v) * T + t) * 2;
-                tab[o] = (float)w[2 * (size_t)idx];
-                tab[o + 1] = (float)w[2 * (size_t)idx + 1];
+                tab[o] = w[2 * (size_t)idx];
+                tab[o + 1] = w[2 * (size_t)idx + 1];
             }
         }
     }
-    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    return SDSP_HIP_OK;
+    return upload_twiddles(tab, precision, dev); // rounds to the plan precision exactly like the row itself
 }
 
 // Thread-twiddle table of fft_big.hip: [pass (A, B)][stage s < 5][thread t < N/32] = W^(t << s) for pass A,
@@ -247,7 +245,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0) {
         fft_reg_args a;
         a.data = data;
-        a.tw = p->tw;
+        a.tw = p->twt_reg;
         a.n = p->n;
         a.radix = p->radix;
         a.batch = batch;
@@ -537,8 +535,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->twiddle_bytes = (uint64_t)n * esize(precision);
         if (!rc && n == 4096 && precision == SDSP_HIP_F32)
             rc = upload_thread_twiddles_4096(w, radix, &p->twt);
-        if (!rc && precision == SDSP_HIP_F32 && fft_reg_supports(n, radix))
-            rc = upload_thread_twiddles_reg(w, n, radix, &p->twt_reg);
+        if (!rc && ((precision == SDSP_HIP_F32 && fft_reg_supports(n, radix)) ||
+                    (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))))
+            rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
             rc = upload_thread_twiddles_big(w, n, &p->twt_big);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);

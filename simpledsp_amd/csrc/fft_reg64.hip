@@ -91,13 +91,12 @@ __global__ __launch_bounds__(points64_for(LOG2N) / 16) void sdsp_fft_reg_f64_ker
         for (int k = 0; k < 16; k++)
             x[k] = lds[slot(p0 + S * k)];
         constexpr bool TW = S > 1;
-        const uint32_t unit = r << (4 * I);
         if constexpr (RADIX == 2) {
             double2 w[4];
             if constexpr (TW) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    w[j] = tw[unit << j];
+                    w[j] = tw[(6 * I + j) * T + t]; // thread-twiddle table, see fft_reg.hip
             }
             passes::r2_pass<REV, TW, is_last ? 4 - LAST : 0>::run(x, w);
         } else {
@@ -105,8 +104,8 @@ __global__ __launch_bounds__(points64_for(LOG2N) / 16) void sdsp_fft_reg_f64_ker
             if constexpr (TW) {
 #pragma unroll
                 for (int q = 1; q < 4; q++) {
-                    w1[q - 1] = tw[unit * q];
-                    w2[q - 1] = tw[unit * 4 * q];
+                    w1[q - 1] = tw[(6 * I + q - 1) * T + t];
+                    w2[q - 1] = tw[(6 * I + q + 2) * T + t];
                 }
             }
             passes::r4_pass<REV, TW, !(is_last && LAST == 2)>(x, w1, w2);
