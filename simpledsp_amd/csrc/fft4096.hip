@@ -318,8 +318,9 @@ struct lds_map {
 };
 
 // all six stages on one transform held as x[k] = element t + 256 k; returns with
-// x[k] = result[t + 256 * (4 (k & 3) + (k >> 2))].  w*: FORWARD twiddles (conjugated here when REV).
-template <bool REV>
+// x[k] = result[t + 256 * (4 (k & 3) + (k >> 2))].  w*: FORWARD twiddles, conjugated here when REV
+// (CONJ = false: the table is already folded for the direction).
+template <bool REV, bool CONJ = REV>
 __device__ __forceinline__ void fft4096_in_regs(float2 (&x)[16], float2 *lds, const lds_map &mp,
                                                 const float2 (&wA1)[3], const float2 (&wA2)[3],
                                                 const float2 (&wB1)[3], const float2 (&wB2)[3])
@@ -327,10 +328,10 @@ __device__ __forceinline__ void fft4096_in_regs(float2 (&x)[16], float2 *lds, co
     float2 a1[3], a2[3], b1[3], b2[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        a1[r] = float2{ wA1[r].x, REV ? -wA1[r].y : wA1[r].y };
-        a2[r] = float2{ wA2[r].x, REV ? -wA2[r].y : wA2[r].y };
-        b1[r] = float2{ wB1[r].x, REV ? -wB1[r].y : wB1[r].y };
-        b2[r] = float2{ wB2[r].x, REV ? -wB2[r].y : wB2[r].y };
+        a1[r] = float2{ wA1[r].x, CONJ ? -wA1[r].y : wA1[r].y };
+        a2[r] = float2{ wA2[r].x, CONJ ? -wA2[r].y : wA2[r].y };
+        b1[r] = float2{ wB1[r].x, CONJ ? -wB1[r].y : wB1[r].y };
+        b2[r] = float2{ wB2[r].x, CONJ ? -wB2[r].y : wB2[r].y };
     }
     two_stages<REV, true, true>(x, a1, a2);
     {
@@ -539,15 +540,15 @@ int cu_count()
 }
 
 template <int PREFETCH, int WAVES, bool NT, int CHUNK = 2>
-void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s)
+void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s, uint32_t pad_lds = 0)
 {
     float2 *d = reinterpret_cast<float2 *>(a.data);
     const float2 *w = reinterpret_cast<const float2 *>(a.tw);
     if (a.reverse)
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), 0, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
                            w, a.batch, a.scale);
     else
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), 0, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
                            w, a.batch, a.scale);
 }
 
@@ -580,6 +581,9 @@ constexpr variant_desc kVariants[] = {
                             //    the last LDS read of a workgroup's only transform kept: 74.1 % where 0 gives 74.9 %
     { false, 3, 0, true },  // 13 as 0 with a barrier right before the stores (keeps the four waves' stores together): 74.8 %
                             //    (squeezing 0 to 96 VGPRs for a fifth workgroup per CU cost 24 B/lane of scratch: 67.7 %)
+    { false, 3, 0, true },  // 14 as 0 with 8 KiB of unused dynamic LDS: caps the CU at 4 workgroups
+    { false, 3, 0, true },  // 15 as 0 with 21 KiB: caps it at 3 (0 / 14 / 15: 74.9 / 75.1 / 75.1 % -- occupancy is not the limiter;
+                            //    a pair kernel that also delays the first transform's stores to make them one 64-KiB burst: 69.5 %)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -660,7 +664,9 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
     case 10: launch_variant<2, 3, true, 8>(a, (a.batch + 7) / 8, s); break;
     case 11: launch_variant<2, 4, true, 2>(a, (a.batch + 1) / 2, s); break;
     case 12: launch_variant<0, 3, true, 1>(a, grid, s); break;
-    default: launch_variant<0, 3, true, 3>(a, grid, s); break;
+    case 13: launch_variant<0, 3, true, 3>(a, grid, s); break;
+    case 14: launch_variant<0, 3, true>(a, grid, s, 8 * 1024); break;  // 40 KiB of LDS: at most 4 workgroups per CU
+    default: launch_variant<0, 3, true>(a, grid, s, 21 * 1024); break; // 53 KiB: at most 3
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
