@@ -150,11 +150,13 @@ __device__ __forceinline__ uint32_t rev4bits(uint32_t v) // reverse the low 4 bi
 
 // PREFETCH: fetch transform i+1 into registers during passes B/C of transform i (costs 32 VGPRs).
 // WAVES: occupancy the register allocator must leave room for (waves per SIMD = workgroups per CU).
-template <bool REV, int PREFETCH, int WAVES, bool NT, int CHUNK = 2>
+template <bool REV, int PREFETCH, int WAVES, int NTP, int CHUNK = 2>
 __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__restrict__ data,
                                                                   const float2 *__restrict__ tw,
                                                                   uint64_t batch, float scale)
 {
+    // NTP: cache policy -- 0 default, 1 non-temporal loads and stores, 2 loads only, 3 stores only
+    constexpr bool NTL = NTP == 1 || NTP == 2, NT = NTP == 1 || NTP == 3;
     // LDS slot of logical position p (8-byte units): p ^ (rev4bits(p >> 8) << 1)
     __shared__ __attribute__((aligned(16))) float2 lds[4096];
 
@@ -203,12 +205,12 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
         const float2 *src = data + f * 4096 + t;
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            x[k] = gload<NT>(src + 256 * k);
+            x[k] = gload<NTL>(src + 256 * k);
         if constexpr (PREFETCH == 2) {
             if (f + 1 < batch) {
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    nx[k] = gload<NT>(src + 4096 + 256 * k);
+                    nx[k] = gload<NTL>(src + 4096 + 256 * k);
             }
         }
     }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
             const float2 *src = data + f * 4096 + t;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                x[k] = gload<NT>(src + 256 * k);
+                x[k] = gload<NTL>(src + 256 * k);
         }
         // ---- pass A: stages 0,1 (groups 1024, 256), fft.h:311-349 with i = 0,1
         two_stages<REV, true, true>(x, wA1, wA2);
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
                 const float2 *src = data + fn * 4096 + t;
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    nx[k] = gload<NT>(src + 256 * k);
+                    nx[k] = gload<NTL>(src + 256 * k);
             }
         }
 
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
                 const float2 *src = data + (fn + 1) * 4096 + t;
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    nx[k] = gload<NT>(src + 256 * k);
+                    nx[k] = gload<NTL>(src + 256 * k);
             }
         }
     }
@@ -539,7 +541,7 @@ int cu_count()
     return cached;
 }
 
-template <int PREFETCH, int WAVES, bool NT, int CHUNK = 2>
+template <int PREFETCH, int WAVES, int NT, int CHUNK = 2>
 void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s, uint32_t pad_lds = 0)
 {
     float2 *d = reinterpret_cast<float2 *>(a.data);
@@ -584,6 +586,10 @@ constexpr variant_desc kVariants[] = {
     { false, 3, 0, true },  // 14 as 0 with 8 KiB of unused dynamic LDS: caps the CU at 4 workgroups
     { false, 3, 0, true },  // 15 as 0 with 21 KiB: caps it at 3 (0 / 14 / 15: 74.9 / 75.1 / 75.1 % -- occupancy is not the limiter;
                             //    a pair kernel that also delays the first transform's stores to make them one 64-KiB burst: 69.5 %)
+    { false, 3, 0, true },  // 16 capped at 2 workgroups per CU
+    { false, 3, 0, true },  // 17 capped at 1 (2 / 1 per CU: 74.7 / 46.4 %: two workgroups per CU already reach the plateau)
+    { false, 3, 0, true },  // 18 non-temporal loads, default-policy stores: 70.9 %
+    { false, 3, 0, true },  // 19 default-policy loads, non-temporal stores: 69.1 % (5, both default: 69.0 %; 0, both nt: 74.8 %)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -666,7 +672,11 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
     case 12: launch_variant<0, 3, true, 1>(a, grid, s); break;
     case 13: launch_variant<0, 3, true, 3>(a, grid, s); break;
     case 14: launch_variant<0, 3, true>(a, grid, s, 8 * 1024); break;  // 40 KiB of LDS: at most 4 workgroups per CU
-    default: launch_variant<0, 3, true>(a, grid, s, 21 * 1024); break; // 53 KiB: at most 3
+    case 15: launch_variant<0, 3, true>(a, grid, s, 21 * 1024); break; // 53 KiB: at most 3
+    case 16: launch_variant<0, 3, true>(a, grid, s, 48 * 1024); break; // 80 KiB: at most 2
+    case 17: launch_variant<0, 3, true>(a, grid, s, 64 * 1024 - 256); break; // 96 KiB: 1
+    case 18: launch_variant<0, 3, 2>(a, grid, s); break; // nt loads, default-policy stores
+    default: launch_variant<0, 3, 3>(a, grid, s); break; // default-policy loads, nt stores
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
