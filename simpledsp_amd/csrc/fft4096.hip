@@ -195,9 +195,8 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     const uint32_t c_x = (xc >> 1) & 7; // pair index i -> i ^ c_x
 
     float2 x[16], nx[PREFETCH ? 16 : 1];
-    // PREFETCH == 2 ("pair"): the workgroup owns transforms 2b and 2b+1 -- 64 contiguous KiB, the shape
-    // whose bare load/store pattern reaches HBM peak (fft_big.hip) -- loads both up front and runs them
-    // one after the other.
+    // PREFETCH == 2 ("pair"): the workgroup owns transforms 2b and 2b+1 (64 contiguous KiB), loads both up
+    // front and runs them one after the other.
     constexpr uint64_t kStep = PREFETCH == 2 ? 1 : 0;
     uint64_t f = PREFETCH == 2 ? CHUNK * (uint64_t)blockIdx.x : blockIdx.x;
     const uint64_t f_end = PREFETCH == 2 ? (f + CHUNK < batch ? f + CHUNK : batch) : batch;
@@ -572,8 +571,8 @@ constexpr variant_desc kVariants[] = {
     { false, 3, 6, true },  // 4 persistent, no prefetch, 2x oversubscribed
     { false, 3, 0, false }, // 5 as 0 with the default cache policy
     { true, 3, 3, false },  // 6 as 2 with the default cache policy
-    { true, 3, 0, true },   // 7 "pair": one workgroup per TWO consecutive transforms (64 KiB -- the chunk whose bare
-                            //   load/store pattern reaches HBM peak), both loaded up front, run one after the other:
+    { true, 3, 0, true },   // 7 "pair": one workgroup per TWO consecutive transforms (64 KiB), both loaded up front, run
+                            //   one after the other:
                             //   74.0 % while twiddles were gathered (it halved that cost), 71.4 % with the table
     { true, 2, 0, true },   // 8 as 7 at 2 per CU
     { true, 3, 0, true },   // 9 four consecutive transforms per workgroup, one transform of loads kept in flight: 69.2 %

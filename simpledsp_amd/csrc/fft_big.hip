@@ -4,9 +4,8 @@
 // These sizes are too large for the register-pass family's "whole tile in LDS" scheme to keep more
 // than one workgroup on a CU (N = 16384 is 128 KiB of complex f32), so nothing overlapped the load and
 // store phases there (44-51 % of HBM peak; this kernel: 67 % at 8192, 60 % at 16384, 41 % at 32768 --
-// where the previous path was the two-pass four-step).  Measured with the butterflies and the exchanges
-// compiled out, the bare load/store pattern of this kernel runs at 97-103 % of 8 TB/s: what is left is the
-// un-overlapped on-chip work between a wave's last load and its first store.  Here the transform lives in REGISTERS, 32 points per
+// where the previous path was the two-pass four-step).  In-place read+write traffic plateaus at 74-77 % of
+// 8 TB/s on this part whatever the shape (tools/delaybench.hip), so what is left here is on-chip work.  Here the transform lives in REGISTERS, 32 points per
 // thread (N/32 threads per transform, one transform per workgroup), and LDS is only the exchange medium
 // between register passes -- moved one plane (real, then imaginary) at a time, so a transform needs
 // 4*N bytes of LDS and TWO workgroups of N = 16384 (four of N = 8192) share a CU:
@@ -47,7 +46,7 @@ template <int L> __device__ __forceinline__ uint32_t sw(uint32_t p)
 }
 
 // G transforms per workgroup (consecutive in memory), each on its own N/32 threads and LDS plane.  G = 1 is what
-// ships: at N = 4096 (where G = 2 gives the 64-KiB chunks whose bare load/store pattern reaches HBM peak) larger
+// ships: at N = 4096 larger
 // workgroups measured slower -- 69.9 % (G = 1), 66.9 % (G = 2), 63.2 % (G = 4) -- the barriers span more waves.
 template <int L, bool REV, bool NT, int G = 1>
 // four waves per SIMD for every size: at N = 8192 that costs 20-36 B/lane of scratch, but three workgroups
