@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_il]
+    python bench.py --workload fft --n 8192 --radix 2 [--precision f64]     (any covered size; not a BASELINE config)
+    python bench.py --workload fir --taps 32                                  (FIR bank; not a BASELINE config)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -39,7 +41,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_il"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_il", "fft", "fir"])
+    ap.add_argument("--n", type=int, default=1024, help="--workload fft: transform size")
+    ap.add_argument("--radix", type=int, default=2, help="--workload fft: 2 or 4")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / fir")
+    ap.add_argument("--taps", type=int, default=32, help="--workload fir: filter length")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the per-GPU unit count")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +101,61 @@ def make_fft1m(sd, torch, dev, args):
         "hbm_passes": info.hbm_passes,
     }
     return step, batch, int(info.algorithmic_bytes), desc, "batched complex FFTs/sec (N=2^20, radix-2, fp32)", "FFT/s", "f32", (fwd, rev, x)
+
+
+def make_fft(sd, torch, dev, args):
+    """any size / radix / precision the library covers (not a BASELINE config): 1 GiB of transforms per GPU"""
+    n, f64 = args.n, args.precision == "f64"
+    batch = args.batch_per_gpu or max(1, (1 << (26 if f64 else 27)) // n)
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 4 + dev.index)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device=dev,
+                                          dtype=torch.float64 if f64 else torch.float32))
+    prec = sd.F64 if f64 else sd.F32
+    fwd = sd.FftPlan(n, args.radix, sd.forward_fft, prec, max_batch=batch, device=dev.index)
+    rev = sd.FftPlan(n, args.radix, sd.reverse_fft, prec, max_batch=batch, device=dev.index)
+    if args.variant >= 0:
+        fwd.set_variant(args.variant)
+        rev.set_variant(args.variant)
+    state = {"i": 0}
+
+    def step():
+        (fwd if state["i"] % 2 == 0 else rev).exec(x)
+        state["i"] += 1
+
+    info = fwd.info
+    desc = {
+        "workload": f"batched N={n} radix-{args.radix} complex FFT, in place, {args.precision} (not a BASELINE config)",
+        "n": n, "radix": args.radix, "batch_per_gpu": batch,
+        "direction": "forward/reverse alternating (keeps the in-place data finite)",
+        "kernel": info.kernel.decode(), "hbm_passes": info.hbm_passes,
+    }
+    return (step, batch, int(info.algorithmic_bytes), desc,
+            f"batched complex FFTs/sec (N={n}, radix-{args.radix}, {args.precision})", "FFT/s", args.precision, (fwd, rev, x))
+
+
+def make_fir(sd, torch, dev, args):
+    """FIR bank (the reference's README TODO) on the BASELINE config-4 shape"""
+    f64 = args.precision == "f64"
+    channels = args.batch_per_gpu or ((1 << 19) if f64 else (1 << 20))
+    samples = 4096
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 5 + dev.index)
+    x = torch.randn((channels, samples), generator=g, device=dev, dtype=torch.float64 if f64 else torch.float32)
+    bank = sd.fir_filter(args.taps, channels, sd.F64 if f64 else sd.F32, device=dev.index)
+    bank.set_lp_coeff(10e3, 100e3)  # unit DC gain: repeated filtering stays bounded
+    if args.variant >= 0:
+        bank.set_variant(args.variant)
+
+    def step():
+        bank.reset()
+        bank.process(x)
+
+    desc = {
+        "workload": f"FIR low-pass bank ({args.taps} taps, Hamming-windowed sinc), channels x 4096 samples, in place "
+                    "(not a BASELINE config; no reference code exists)",
+        "taps": args.taps, "channels_per_gpu": channels, "samples": samples, "kernel": "sdsp_fir_kernel",
+    }
+    return (step, channels * samples, 16 if f64 else 8, desc, f"FIR samples/sec ({args.taps} taps)", "samples/s",
+            args.precision, (bank, x))
 
 
 def make_iir(sd, torch, dev, args, f64=False, interleaved=False):
@@ -227,7 +288,7 @@ def main():
 
     mk = {"fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
           "iir64": lambda *a: make_iir(*a, f64=True),
-          "iir_il": lambda *a: make_iir(*a, interleaved=True)}[args.workload]
+          "iir_il": lambda *a: make_iir(*a, interleaved=True), "fft": make_fft, "fir": make_fir}[args.workload]
     step, units, unit_bytes, desc, metric, unit, dtype, keep = mk(sd, torch, dev, args)
 
     # Setup, not measurement: wake the device up.  The first ~20 back-to-back launches after idle run
@@ -272,7 +333,8 @@ def main():
                 "algorithmic_bytes_per_launch": units * unit_bytes,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        # the extra workloads (--workload fft / fir) are not BASELINE configs: no CPU leg for them
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ("fft", "fir"):
             del keep
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
