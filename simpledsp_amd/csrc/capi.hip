@@ -789,6 +789,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->n == 4096 && p->radix == 2 && p->variant == 3 && !p->real_mode)
+        name = "sdsp_fft4096_r2_f32"; // its two-transforms-per-workgroup variant
     if (big)
         name = "sdsp_fft_big_kernel";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
