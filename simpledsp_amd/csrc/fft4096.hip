@@ -150,7 +150,11 @@ __device__ __forceinline__ uint32_t rev4bits(uint32_t v) // reverse the low 4 bi
 
 // PREFETCH: fetch transform i+1 into registers during passes B/C of transform i (costs 32 VGPRs).
 // WAVES: occupancy the register allocator must leave room for (waves per SIMD = workgroups per CU).
-template <bool REV, int PREFETCH, int WAVES, int NTP, int CHUNK = 2>
+// ORD: the order in which a thread issues its 16 row loads / row stores (rows are 2 KiB apart):
+//   0 loads ascending, stores 0,4,8,12,1,5,...   1 both bit-reversed   2 both (5j+3) mod 16
+//   3 loads ascending, stores (5j+3) mod 16      4 loads (5j+3) mod 16, stores as 0
+constexpr int row_order(int ord, int j) { return ord == 1 ? ((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) : (5 * j + 3) % 16; }
+template <bool REV, int PREFETCH, int WAVES, int NTP, int CHUNK = 2, int ORD = 0>
 __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__restrict__ data,
                                                                   const float2 *__restrict__ tw,
                                                                   uint64_t batch, float scale)
@@ -217,8 +221,10 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
         if constexpr (!PREFETCH) {
             const float2 *src = data + f * 4096 + t;
 #pragma unroll
-            for (int k = 0; k < 16; k++)
+            for (int j = 0; j < 16; j++) {
+                const int k = (ORD == 1 || ORD == 2 || ORD == 4) ? row_order(ORD == 4 ? 2 : ORD, j) : j;
                 x[k] = gload<NTL>(src + 256 * k);
+            }
         }
         // ---- pass A: stages 0,1 (groups 1024, 256), fft.h:311-349 with i = 0,1
         two_stages<REV, true, true>(x, wA1, wA2);
@@ -280,7 +286,10 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             // CHUNK == 1 (variant 12): issue the stores in ascending address order
-            const int k = (PREFETCH == 0 && CHUNK == 1) ? 4 * (j & 3) + (j >> 2) : j;
+            // ORD 1..3: the row sequence is row_order(j); register k = 4 (row & 3) + (row >> 2) holds that row
+            constexpr int kOrdS = ORD == 3 ? 2 : ORD;
+            const int rj = row_order(kOrdS, j);
+            const int k = (ORD >= 1 && ORD <= 3) ? 4 * (rj & 3) + (rj >> 2) : (PREFETCH == 0 && CHUNK == 1) ? 4 * (j & 3) + (j >> 2) : j;
             float2 v = x[k];
             if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
                 v.x *= scale;
@@ -540,16 +549,16 @@ int cu_count()
     return cached;
 }
 
-template <int PREFETCH, int WAVES, int NT, int CHUNK = 2>
+template <int PREFETCH, int WAVES, int NT, int CHUNK = 2, int ORD = 0>
 void launch_variant(const fft4096_args &a, uint64_t grid, hipStream_t s, uint32_t pad_lds = 0)
 {
     float2 *d = reinterpret_cast<float2 *>(a.data);
     const float2 *w = reinterpret_cast<const float2 *>(a.tw);
     if (a.reverse)
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, PREFETCH, WAVES, NT, CHUNK, ORD>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
                            w, a.batch, a.scale);
     else
-        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT, CHUNK>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
+        hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, PREFETCH, WAVES, NT, CHUNK, ORD>), dim3((uint32_t)grid), dim3(256), pad_lds, s, d,
                            w, a.batch, a.scale);
 }
 
@@ -589,6 +598,10 @@ constexpr variant_desc kVariants[] = {
     { false, 3, 0, true },  // 17 capped at 1 (2 / 1 per CU: 74.7 / 46.4 %: two workgroups per CU already reach the plateau)
     { false, 3, 0, true },  // 18 non-temporal loads, default-policy stores: 70.9 %
     { false, 3, 0, true },  // 19 default-policy loads, non-temporal stores: 69.1 % (5, both default: 69.0 %; 0, both nt: 74.8 %)
+    { false, 3, 0, true },  // 20 row order: loads and stores bit-reversed: 75.3 % where 0 gives 74.6 % in the same run
+    { false, 3, 0, true },  // 21 loads and stores (5j+3) mod 16: 74.4 %
+    { false, 3, 0, true },  // 22 loads ascending, stores (5j+3) mod 16: 74.9 %
+    { false, 3, 0, true },  // 23 loads (5j+3) mod 16, stores as 0: 74.2 % -- the order of a thread's rows is worth < 1 point
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 } // namespace
@@ -675,7 +688,11 @@ int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream)
     case 16: launch_variant<0, 3, true>(a, grid, s, 48 * 1024); break; // 80 KiB: at most 2
     case 17: launch_variant<0, 3, true>(a, grid, s, 64 * 1024 - 256); break; // 96 KiB: 1
     case 18: launch_variant<0, 3, 2>(a, grid, s); break; // nt loads, default-policy stores
-    default: launch_variant<0, 3, 3>(a, grid, s); break; // default-policy loads, nt stores
+    case 19: launch_variant<0, 3, 3>(a, grid, s); break; // default-policy loads, nt stores
+    case 20: launch_variant<0, 3, 1, 2, 1>(a, grid, s); break;
+    case 21: launch_variant<0, 3, 1, 2, 2>(a, grid, s); break;
+    case 22: launch_variant<0, 3, 1, 2, 3>(a, grid, s); break;
+    default: launch_variant<0, 3, 1, 2, 4>(a, grid, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -178,7 +178,7 @@ def test_fft4096_ragged_batches_all_variants(sd, torch_cuda, oracle, batch):
     for T, ref in ((sd.forward_fft, want), (sd.reverse_fft, want_rev)):
         plan = sd.FftPlan(4096, 4, T, sd.F32, max_batch=batch)
         assert plan.info.kernel.decode().startswith("sdsp_fft4096_r4_f32")
-        for variant in range(20):  # 7..19: two consecutive transforms per workgroup (ragged: odd batches)
+        for variant in range(24):  # 7..23: two consecutive transforms per workgroup (ragged: odd batches)
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
