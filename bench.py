@@ -267,6 +267,11 @@ def read_traffic(kernels: str):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON: libraries that chat on fd 1 (RCCL prints a version banner
+    # there at communicator creation) are sent to stderr for the whole run; the JSON goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import simpledsp_amd as sd
 
@@ -340,7 +345,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if out["cpu_baseline"]["value"]:
                 out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

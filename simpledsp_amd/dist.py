@@ -32,6 +32,11 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callabl
     the closing barrier -- so the maximum is the whole job's time without charging the barrier's own
     latency (~2 ms for RCCL) to the steps."""
     import torch
+    if dist is not None:
+        # not the bracketing barrier: the FIRST collective of a process costs milliseconds (kernel load,
+        # channel setup); taken here, before the warm-up, it leaves the bracketing barrier below at tens of
+        # microseconds -- short enough that the device does not drop out of its steady clocks before step 1
+        dist.barrier()
     for _ in range(warmup):
         step()
     sync()
