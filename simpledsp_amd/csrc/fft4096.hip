@@ -11,14 +11,17 @@
 //     every ds_write_b64 / ds_read_b64 / ds_read_b128 of all three access patterns is bank-conflict
 //     free without padding; the butterflies are in place, so a thread rewrites only slots it read.
 //   * the twiddle W_N^(r*pos) that stage s owes stage s+1 factors into a per-thread part that is the
-//     same for every transform (W^(r*t): 12 complex values, fetched ONCE per workgroup from the
-//     HBM-resident table the plan precomputed in double) and a compile-time W_16 constant.  No
-//     twiddle traffic per transform.
+//     same for every transform (W^(r*t): 12 complex values per thread, read with coalesced loads from the
+//     plan's thread-twiddle table -- the values of the row W_4096^j, precomputed in double, laid out
+//     [value][thread]) and a compile-time W_16 constant.
 //   * the digit reversal costs nothing: the last pass is assigned so that thread t holds the block
 //     whose outputs land at t + 256*j, i.e. stores are as coalesced as the loads (512 contiguous
 //     bytes per wave instruction both ways) and HBM sees every element exactly once each way.
-//   * workgroups are persistent (grid = resident capacity) and fetch transform i+1 into registers
-//     while transform i is in its second and third pass, so every wave always has loads in flight.
+//   * one workgroup per transform, streaming (non-temporal) loads and stores: 74.9 % of the 8 TB/s HBM
+//     peak, which is where in-place read+write traffic plateaus on this part whatever its shape
+//     (tools/delaybench.hip).  The variant table at the bottom keeps what was tried instead -- persistent
+//     workgroups with register prefetch, two or more consecutive transforms per workgroup, occupancy caps,
+//     cache policies, row orders -- with the measured result of each.
 //
 // HBM-bound by design: 64 KiB of traffic against ~250 kflop per transform.  No MFMA.
 #include <hip/hip_runtime.h>
