@@ -170,6 +170,8 @@ struct sdsp_hip_fft_plan {
     hipStream_t aux_stream = nullptr;
     std::vector<hipEvent_t> events;
     sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
+    sdsp_hip_fft_plan *mid_rows = nullptr; // N = 2^16 .. 2^19 f32: plan of the 16 row transforms (fft_mid.hip)
+    void *tw1024 = nullptr;                // ... and W_1024^j, the coarse factor of its inter-pass twiddle
     int real_mode = 0;                    // 0 complex; 1 real forward; 2 real inverse (n = n_real / 2)
 };
 
@@ -355,6 +357,24 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         // the caller's stream is complete only when every pass 2 is
         for (uint64_t i = (n_chunks >= 2 ? n_chunks - 2 : 0); i < n_chunks; i++)
             HIP_TRY(hipStreamWaitEvent(stream, p->events[2 * i + 1], 0));
+        return SDSP_HIP_OK;
+    }
+
+    // N = 2^16 .. 2^19, f32: three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel
+    if (p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0) {
+        const uint32_t n2 = p->n / 16;
+        uint64_t done = 0;
+        while (done < batch) {
+            const uint64_t nb = std::min<uint64_t>(p->ws_batch, batch - done);
+            char *d = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
+            if (int rc = launch_fft_mid_cols(d, p->workspace, p->tw1024, n2, nb, rev, stream))
+                return rc;
+            if (int rc = fft_exec_device(p->mid_rows, p->workspace, nb * 16, stream))
+                return rc;
+            if (int rc = launch_fft_mid_untwist(p->workspace, d, n2, nb, stream))
+                return rc;
+            done += nb;
+        }
         return SDSP_HIP_OK;
     }
 
@@ -577,6 +597,15 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
         }
     }
+    if (!rc && p->path == PATH_FOUR_STEP && precision == SDSP_HIP_F32 && n >= (1u << 16) && n <= (1u << 19)) {
+        const uint32_t n2 = n / 16;
+        const int sub_radix = (radix == 4 && sdsp_hip_is_power_of_4(n2)) ? 4 : 2;
+        rc = sdsp_hip_fft_plan_create(&p->mid_rows, n2, sub_radix, direction, precision, p->ws_batch * 16, device);
+        if (!rc) {
+            make_twiddles(1024, direction, w);
+            rc = upload_twiddles(w, precision, &p->tw1024);
+        }
+    }
     if (rc) {
         sdsp_hip_fft_plan_destroy(p);
         return rc;
@@ -627,11 +656,15 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->twt);
         (void)hipFree(p->twt_reg);
         (void)hipFree(p->twt_big);
+        (void)hipFree(p->tw1024);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
         if (p->partner)
             sdsp_hip_fft_plan_destroy(p->partner);
         p->partner = nullptr;
+        if (p->mid_rows)
+            sdsp_hip_fft_plan_destroy(p->mid_rows);
+        p->mid_rows = nullptr;
         (void)hipSetDevice(p->device);
         for (hipEvent_t e : p->events)
             (void)hipEventDestroy(e);
@@ -777,7 +810,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->device = p->device;
     const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
                      !p->real_mode && fft_big_supports(p->n, p->radix);
-    info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
+    const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0;
+    info->hbm_passes = mid ? 3 : ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
     info->algorithmic_bytes = 2ull * p->n * esize(p->precision); // real plans: n complex = n_real floats, same bytes
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;
@@ -793,6 +827,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = "sdsp_fft4096_r2_f32"; // its two-transforms-per-workgroup variant
     if (big)
         name = "sdsp_fft_big_kernel";
+    if (mid)
+        name = "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

@@ -1,0 +1,144 @@
+// fft_mid.hip -- the two streaming passes of the three-pass schedule for N = 2^16 .. 2^19, f32, on gfx950.
+//
+// These sizes exceed what one workgroup can hold, and the general four-step through the coverage kernel
+// reaches only 7-15 % of HBM peak.  With N = 16 x N2 (N2 = 4096 .. 32768, i.e. a size one of the tuned
+// single-pass kernels covers) the transform becomes
+//
+//   pass 1  sdsp_fft_col16_kernel   for every n2: the 16-point DFT down the column (row stride N2), times the
+//                                   inter-pass twiddle W_N^(n2*k1)  (fft.h:286's factor for the combined
+//                                   stages), data -> workspace.  One lane = two adjacent columns, every
+//                                   access a 1 KiB contiguous piece of a row per wave instruction.
+//   pass 2  (existing kernels)      16 contiguous length-N2 transforms per big transform, in place in the
+//                                   workspace: fft4096.hip / fft_big.hip, 16 x batch of them in one launch
+//   pass 3  sdsp_fft_untwist16      X[k1 + 16 k2] = Z[k1][k2]: a [16][N2] -> [N2][16] transpose through LDS,
+//                                   workspace -> data; 2 KiB pieces in, 32 KiB contiguous out
+//
+// Three passes over HBM instead of one, each at 60-75 % of the peak: 20-25 % of the compulsory-bytes roofline
+// (N = 65536: 24.6 % where the four-step through the coverage kernel gave 14.5 %; N = 262144: 23.5 % vs 7 %).
+#include <hip/hip_runtime.h>
+
+#include "fft_passes.h"
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// pass 1: thread = columns (2c, 2c+1) of one transform; x[k] / y[k] = row k of those columns.
+// Inter-pass twiddle W_N^m, m = n2*k1 < N = 2^L, as in fft1m.hip: coarse factor W_1024^(m >> (L-10)) from an LDS
+// copy of the 1024-entry table, fine factor (angle below 2 pi / 1024) from two series terms -- exact to fp32
+// rounding, and no gathers from the N-entry row (they cost more cache-line requests than the data).
+template <bool REV>
+__global__ __launch_bounds__(256) void sdsp_fft_col16_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                             const float2 *__restrict__ tw1024, uint32_t n2, float scale,
+                                                             uint32_t fine_bits, float fine_step)
+{
+    __shared__ float2 w1k[1024];
+    reinterpret_cast<float4 *>(w1k)[threadIdx.x] = reinterpret_cast<const float4 *>(tw1024)[threadIdx.x];
+    reinterpret_cast<float4 *>(w1k)[threadIdx.x + 256] = reinterpret_cast<const float4 *>(tw1024)[threadIdx.x + 256];
+    __syncthreads();
+    auto twiddle = [&](uint32_t m) {
+        const float th = (float)(m & ((1u << fine_bits) - 1)) * fine_step; // < 2 pi / 1024
+        const float th2 = th * th;
+        const float sn = th - th * th2 * 0.16666667f;
+        const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
+        return passes::cmul(w1k[m >> fine_bits], fine);
+    };
+    const uint32_t pairs = n2 / 2;                                  // column pairs per transform
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; // over transforms x column pairs (exact grid)
+    const uint64_t xform = gid / pairs;
+    const uint32_t c = (uint32_t)(gid % pairs) * 2;
+    const uint64_t base = xform * 16ull * n2 + c;
+    float2 x[16], y[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(in + base + (uint64_t)k * n2));
+        x[k] = float2{ v.x, v.y };
+        y[k] = float2{ v.z, v.w };
+    }
+    const float2 none[4] = {};
+    passes::r2_pass<REV, false, 0>::run(x, none); // register k now holds output bit_reverse4(k)
+    passes::r2_pass<REV, false, 0>::run(y, none);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t k1 = __brev((uint32_t)k) >> 28;
+        float2 a = x[k], b = y[k];
+        if (k1 != 0) { // W_N^(n2 * k1), N = 16 * n2: exponent < N
+            a = passes::cmul(a, twiddle(c * k1));
+            b = passes::cmul(b, twiddle((c + 1) * k1));
+        }
+        if constexpr (REV) { // the row transforms scale by 1/N2; the remaining 1/16 of reverse_fft::ScaleValues
+            a.x *= scale; a.y *= scale;
+            b.x *= scale; b.y *= scale;
+        }
+        // default cache policy: pass 2 reads this back at once
+        *reinterpret_cast<float4 *>(out + base + (uint64_t)k1 * n2) = float4{ a.x, a.y, b.x, b.y };
+    }
+}
+
+// pass 3: workgroup = 256 consecutive k2 of one transform: in[k1][k2] -> out[k2*16 + k1]
+constexpr int kPitch = 257; // float2 elements per LDS row (odd: the transposed reads spread over the banks)
+__global__ __launch_bounds__(256) void sdsp_fft_untwist16(const float2 *__restrict__ in, float2 *__restrict__ out, uint32_t n2)
+{
+    __shared__ float2 tile[16 * kPitch];
+    const uint32_t t = threadIdx.x;
+    const uint32_t blocks_per_xform = n2 / 256;
+    const uint64_t xform = blockIdx.x / blocks_per_xform;
+    const uint32_t k2_0 = (blockIdx.x % blocks_per_xform) * 256;
+    const float2 *src = in + xform * 16ull * n2 + k2_0 + t;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        tile[r * kPitch + t] = src[(uint64_t)r * n2]; // default policy: just written by pass 2
+    __syncthreads();
+    float2 *dst = out + xform * 16ull * n2 + (uint64_t)k2_0 * 16;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t e = 2 * (t + 256 * j); // output element within the 4096 of this workgroup
+        const uint32_t k2 = e >> 4, k1 = e & 15;
+        const float2 a = tile[k1 * kPitch + k2], b = tile[(k1 + 1) * kPitch + k2];
+        const v4f_t v = { a.x, a.y, b.x, b.y };
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(dst + e));
+    }
+}
+} // namespace
+
+int launch_fft_mid_cols(const void *in, void *out, const void *tw /* W_1024^j */, uint32_t n2, uint64_t batch, int reverse, void *stream)
+{
+    const uint64_t threads = batch * (n2 / 2);
+    const uint64_t blocks = threads / 256; // n2 >= 4096: exact
+    if (blocks == 0 || blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float2 *i = reinterpret_cast<const float2 *>(in);
+    float2 *o = reinterpret_cast<float2 *>(out);
+    const float2 *w = reinterpret_cast<const float2 *>(tw);
+    const uint32_t log2n = sdsp_hip_log2(n2) + 4, fine_bits = log2n - 10;
+    const float fine_step = (float)(6.283185307179586476925 / (double)(16ull * n2)); // 2 pi / N
+    if (reverse)
+        hipLaunchKernelGGL(sdsp_fft_col16_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, s, i, o, w, n2, 1.0f / 16.0f,
+                           fine_bits, fine_step);
+    else
+        hipLaunchKernelGGL(sdsp_fft_col16_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, s, i, o, w, n2, 1.0f, fine_bits,
+                           fine_step);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_mid cols launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
+int launch_fft_mid_untwist(const void *in, void *out, uint32_t n2, uint64_t batch, void *stream)
+{
+    const uint64_t blocks = batch * (n2 / 256);
+    if (blocks == 0 || blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sdsp_fft_untwist16, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const float2 *>(in),
+                       reinterpret_cast<float2 *>(out), n2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_mid untwist launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+} // namespace sdsp_hip
