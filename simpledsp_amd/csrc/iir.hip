@@ -426,6 +426,9 @@ template <typename R, int VEC, bool NT> __device__ __forceinline__ void gstore_c
     }
 }
 
+// U rows are being filtered while the next U are in flight (double buffer).  Measured with 16-byte lanes on the
+// BASELINE config-4 shape: U = 2: 51 %, 4: 63 %, 8: 66 % of HBM peak; a single ring of 8 / 16 row registers that
+// is refilled row by row (same rows in flight, half the registers): 62 % / 61 %.
 template <typename R, int KIND, int M, bool NT, int VEC, int U>
 __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R, M> p)
 {
@@ -605,8 +608,8 @@ int launch_il_v(const iir_args &a, bool nt, hipStream_t stream)
         return fail(SDSP_HIP_ERR_HIP, std::string("iir interleaved launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
-// variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming
-// (measured 63.9 % of HBM peak, round 1); 1 = 8-byte lanes, streaming (58 %); 2 = 8-byte lanes,
+// variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming, eight rows in
+// flight (measured 65.9 % of HBM peak, round 1; 4 = the same with four rows: 63.3 %); 1 = 8-byte lanes, streaming (58 %); 2 = 8-byte lanes,
 // default cache policy (57 %); 3 = 4-byte lanes, f32 only (58 %).  Narrower shapes fall through.
 template <typename R, int KIND, int M> int launch_il_km(const iir_args &a, int variant, hipStream_t stream)
 {
@@ -614,6 +617,8 @@ template <typename R, int KIND, int M> int launch_il_km(const iir_args &a, int v
     const bool a16 = !((uintptr_t)a.data % 16) && !((a.stride * sizeof(R)) % 16) && !(a.channels % V16);
     const bool a8 = !((uintptr_t)a.data % 8) && !((a.stride * sizeof(R)) % 8) && !(a.channels % V8);
     if (variant == 0 && a16)
+        return launch_il_v<R, KIND, M, V16, 8>(a, true, stream);
+    if (variant == 4 && a16) // 16-byte lanes, four rows in flight per wave (the default until U = 8 measured +2.6 points)
         return launch_il_v<R, KIND, M, V16, 4>(a, true, stream);
     if constexpr (sizeof(R) == 4) {
         if (variant == 3 || !a8)
