@@ -59,6 +59,7 @@ typedef enum {
 } sdsp_hip_iir_kind;
 
 #define SDSP_HIP_MAX_SECTIONS 16
+#define SDSP_HIP_RADIX_AUTO 0
 #define SDSP_HIP_FIR_MAX_TAPS 4096
 
 typedef struct sdsp_hip_fft_plan sdsp_hip_fft_plan;
@@ -94,6 +95,8 @@ int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
 /*
  * Replaces sdsp::fft_radix2<T,N> (fft.h:258-299, radix = 2, n a power of 2) and
  * sdsp::fft_radix4<T,N> (fft.h:301-360, radix = 4, n a power of 4) for a BATCH of transforms.
+ * radix = SDSP_HIP_RADIX_AUTO (0) picks radix 4 when n is a power of 4 and radix 2 otherwise (any power of
+ * two through one entry).
  * n must satisfy the radix (else SDSP_HIP_ERR_INVALID_SIZE -- the run-time form of the
  * reference's static_asserts).  `max_batch` sizes the plan-owned workspace that transforms too
  * large for on-chip memory need (n > 16384 in f32, n > 8192 in f64); larger batches are

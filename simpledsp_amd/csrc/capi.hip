@@ -509,6 +509,13 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     if (!out)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
     *out = nullptr;
+    // radix 0 (SDSP_HIP_RADIX_AUTO): radix-4 stages where n is a power of 4, radix-2 stages otherwise -- the
+    // "mixed" entry of SURVEY 8(f)-4: any power of two without the caller choosing the function
+    if (radix == SDSP_HIP_RADIX_AUTO) {
+        if (!sdsp_hip_is_power_of_2(n))
+            return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
+        radix = sdsp_hip_is_power_of_4(n) ? 4 : 2;
+    }
     // the reference's static_asserts (fft.h:261, :304) as run-time checks
     if (radix == 2) {
         if (!sdsp_hip_is_power_of_2(n))

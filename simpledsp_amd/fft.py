@@ -95,6 +95,8 @@ class FftPlan:
         L.check(self._lib.sdsp_hip_fft_plan_create(C.byref(self._h), n, radix, T.direction, precision,
                                                     max_batch, device))
         self.n, self.radix, self.direction, self.precision, self.device = n, radix, T.direction, precision, device
+        if radix == 0:  # SDSP_HIP_RADIX_AUTO: the library chose
+            self.radix = int(self.info.radix)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -150,6 +150,8 @@ def test_preload_matches_reference_fixtures(iir_golden):
 def test_error_codes_replace_static_asserts():
     lib = sd.load()
     h = C.c_void_p()
+    # radix 0 = auto still validates the size before any device is touched
+    assert lib.sdsp_hip_fft_plan_create(C.byref(h), 96, 0, 1, 0, 1, 0) == L.ERR_INVALID_SIZE
     # invalid sizes are rejected before any device is touched: fft.h:261,304
     assert lib.sdsp_hip_fft_plan_create(C.byref(h), 96, 2, 1, 0, 1, 0) == L.ERR_INVALID_SIZE
     assert b"power of 2" in lib.sdsp_hip_last_error_string()

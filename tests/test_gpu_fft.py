@@ -161,6 +161,19 @@ def test_fft4096_radix2_tuned_kernel(sd, torch_cuda, oracle, batch):
         assert rel_max_err(d.cpu().numpy()[pick], want) < TOL32
 
 
+def test_radix_auto_picks_the_stage_type(sd, torch_cuda, oracle):
+    # SDSP_HIP_RADIX_AUTO (0): radix 4 where n is a power of 4, radix 2 otherwise (SURVEY 8f-4 "mixed" entry)
+    rng = np.random.default_rng(5)
+    for n, want_radix in ((1024, 4), (2048, 2), (4096, 4), (8192, 2)):
+        plan = sd.FftPlan(n, 0, sd.forward_fft, sd.F32, max_batch=3)
+        assert plan.info.radix == want_radix
+        x = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))).astype(np.complex64)
+        d = torch_cuda.from_numpy(x).cuda()
+        plan.exec(d)
+        torch_cuda.cuda.synchronize()
+        assert rel_max_err(d.cpu().numpy(), oracle.fft(x.astype(np.complex128), want_radix)) < TOL32
+
+
 def test_n1_is_identity(sd, torch_cuda):
     x = np.array([[1 + 2j], [3 - 1j]], np.complex64)
     assert np.array_equal(_run(sd, torch_cuda, x, 2, sd.forward_fft, sd.F32), x)
