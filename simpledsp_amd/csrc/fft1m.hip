@@ -46,11 +46,12 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
                                                                const float2 *__restrict__ tw_1024, // W_1024^j
                                                                uint32_t tiles_per_transform)
 {
-    // dynamic LDS (72 KiB > the 64 KiB static limit): one real plane [row][col] with rows pair-swapped
-    // by row bit 5, then W_1024^j staged in LDS because it is gathered 37x per thread
+    // dynamic LDS (76 KiB > the 64 KiB static limit): one real plane [row][col] with rows pair-swapped
+    // by row bit 5, then W_1024^j staged in LDS, then the column part of the inter-pass twiddle
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
     float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
     float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + 1024 * kTile * sizeof(float));
+    float2 *qtab = w1k + 1024; // [j][column]: W_N^(32 * n2 * j), the part of the inter-pass twiddle a column shares
     const uint32_t t = threadIdx.x;
     const uint32_t c = t & 15, u = t >> 4;
     reinterpret_cast<float4 *>(w1k)[t] = reinterpret_cast<const float4 *>(tw_1024)[t];
@@ -69,6 +70,21 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
         x[k] = nt_load(at(src_tile + 32768 * k, toff));
 
     __syncthreads();
+    // W_N^m = W_1024^(m >> 10) * W_N^(m & 1023).  The coarse factor comes from the LDS table; the fine factor
+    // has an angle below 2*pi/1024 = 0.0062 rad, where cos = 1 - t^2/2 and sin = t - t^3/6 are exact to fp32
+    // rounding (next terms < 6e-11): no second gather.
+    auto twiddle = [&](uint32_t m) {
+        const float th = (float)(m & 1023) * 5.9921124526782858e-06f; // 2*pi / 2^20
+        const float th2 = th * th;
+        const float sn = th - th * th2 * 0.16666667f;
+        const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
+        return cmul(w1k[m >> 10], fine);
+    };
+    // The inter-pass twiddle of output k1 = 32 j + bu of column n2 is W_N^(n2 bu) * W_N^(32 n2 j): the first
+    // factor is one value per thread, the second is shared by the 32 threads of a column -- 16 x 32 values per
+    // workgroup, one per thread, parked in LDS (read back after the exchange barriers below).  That replaces a
+    // polynomial and a conflict-prone table gather per ELEMENT by one conflict-free LDS read and one multiply.
+    qtab[u * 16 + c] = twiddle(32u * n2 * u); // thread (c, u) computes j = u
     fft32_dif<REV, true>(x, w1k, u); // stages with row strides 512 .. 32; twiddles W_1024^(2^s u)
 
     // exchange rows {u + 32k} -> {32u + k}.  slot(row, col) = (row*16 + col) ^ (((row >> 5) & 1) << 4).
@@ -102,20 +118,13 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__r
     // row k1 of the intermediate matrix (default cache policy: it should stay in the Infinity Cache)
     const uint32_t bu = brev5(u);
     const uint32_t soff = (bu * 1024 + c) * 8u; // bytes
+    const float2 pw = twiddle(n2 * bu); // W_N^(n2 bu)
+    const float2 *const qcol = qtab + c;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
-        if ((k & 7) == 0) // keep at most 8 elements' table fetches in flight (register budget)
+        if ((k & 7) == 0) // keep at most 8 elements' table reads in flight (register budget)
             __builtin_amdgcn_sched_barrier(0);
-        const uint32_t k1 = ((__brev((uint32_t)k) >> 27) << 5) | bu;
-        const uint32_t m = n2 * k1; // < 2^20
-        // W_N^m = W_1024^(m >> 10) * W_N^(m & 1023).  The coarse factor comes from the LDS table; the
-        // fine factor has an angle below 2*pi/1024 = 0.0062 rad, where cos = 1 - t^2/2 and
-        // sin = t - t^3/6 are exact to fp32 rounding (next terms < 6e-11): no second gather.
-        const float th = (float)(m & 1023) * 5.9921124526782858e-06f; // 2*pi / 2^20
-        const float th2 = th * th;
-        const float sn = th - th * th2 * 0.16666667f;
-        const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
-        const float2 tw = cmul(w1k[m >> 10], fine);
+        const float2 tw = cmul(pw, qcol[16 * (int)(__brev((uint32_t)k) >> 27)]); // k1 = 32 * bit_reverse5(k) + bu
         // default cache policy on purpose: a streaming (nt) store here measured 13 % slower overall,
         // the intermediate is re-read from the Infinity Cache by pass 2
         *at(dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27), soff) = cmul(x[k], tw);
@@ -217,7 +226,7 @@ int launch_fft1m_pass(const fft1m_args &a, int which, void *stream)
     float2 *ws = reinterpret_cast<float2 *>(a.workspace);
     const float2 *twn = reinterpret_cast<const float2 *>(a.tw_n);
     const float2 *tw1k = reinterpret_cast<const float2 *>(a.tw_1024);
-    constexpr size_t kColsLds = 1024 * kTile * sizeof(float) + 1024 * sizeof(float2);
+    constexpr size_t kColsLds = 1024 * kTile * sizeof(float) + 1024 * sizeof(float2) + 32 * kTile * sizeof(float2);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sdsp_fft1m_cols<true>),
