@@ -82,7 +82,9 @@ for case in range(cases):
             ftype = int(rng.integers(1, 5))
             spec_kind = ftype if (ftype < 4 and rng.random() < 0.5) else sd.IIR_GENERIC
             bank = sd.casc_2o_iir(m, channels, sd.F64 if f64 else sd.F32, spec_kind)
-            args = (float(rng.uniform(500, 20e3)), 100e3)
+            # f32 recursions lose accuracy as the poles approach z = 1 (1.3e-4 at f0/fs = 200/39000): the
+            # f32 cases stay in the BASELINE filter's neighbourhood, the f64 cases (bit-exact) roam
+            args = (float(rng.uniform(500, 20e3) if f64 else rng.uniform(8e3, 20e3)), 100e3)
             {1: lambda: bank.set_lp_coeff(*args), 2: lambda: bank.set_hp_coeff(*args), 3: lambda: bank.set_bp_coeff(*args, 1.3),
              4: lambda: bank.set_bs_coeff(*args, 1.3)}[ftype]()
             bank.set_variant(int(rng.integers(0, 7)))
@@ -108,7 +110,7 @@ for case in range(cases):
                 # untouched padding stays untouched
                 if not np.array_equal(got[c, :off], x[c, :off]) or not np.array_equal(got[c, off + samples:], x[c, off + samples:]):
                     err = 9.0
-            tol = 0.5 if f64 else 5e-6  # f32: narrow filters amplify rounding (f0/fs small); the BASELINE filter is held to 1e-6
+            tol = 0.5 if f64 else 3e-6  # 8 sections accumulate more rounding than the 4 of the BASELINE filter (1e-6)
             desc = f"iir m={m} {'f64' if f64 else 'f32'} ch={channels} n={samples} pad={pad} off={off} type={ftype} kind={spec_kind} var={bank._variant}"
         else:
             taps = int(rng.integers(1, 200))
