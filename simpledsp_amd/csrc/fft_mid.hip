@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void sdsp_fft_col16_kernel(const float2 *__res
 }
 
 // pass 3: workgroup = 256 consecutive k2 of one transform: in[k1][k2] -> out[k2*16 + k1]
-constexpr int kPitch = 257; // float2 elements per LDS row (odd: the transposed reads spread over the banks)
+// float2 elements per LDS row.  The transposed ds_read_b64 of lane t touches row 2 (t & 7) (+1), column (t >> 3) + 32 j:
+// within a 32-lane group the bank pair index is (2 (t & 7) P + (t >> 3)) mod 32, distinct for P = 2 (mod 32) (4 a + b);
+// P = 257 measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 25 %.
+constexpr int kPitch = 258;
 __global__ __launch_bounds__(256) void sdsp_fft_untwist16(const float2 *__restrict__ in, float2 *__restrict__ out, uint32_t n2)
 {
     __shared__ float2 tile[16 * kPitch];
