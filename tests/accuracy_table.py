@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measured parity margins: normwise error max|got-ref|/max|ref| (SURVEY 8d metric) of every f32 kernel against
+"""(Test infrastructure: uses the oracle, hence it lives under tests/.)  Measured parity margins: normwise error max|got-ref|/max|ref| (SURVEY 8d metric) of every f32 kernel against
 the double-precision oracle on seeded random input, next to the 1e-6 bound the tests enforce."""
 import sys
 from pathlib import Path

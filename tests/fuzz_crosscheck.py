@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised cross-check of the C-ABI paths against numpy / the oracle: shapes, strides, offsets, variants.
-   tools/fuzz.py [seed] [cases]"""
+"""(Test infrastructure: uses the oracle, hence it lives under tests/.)  Randomised cross-check of the C-ABI paths against numpy / the oracle: shapes, strides, offsets, variants.
+   tests/fuzz_crosscheck.py [seed] [cases]"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -266,10 +266,10 @@ def test_baseline_config4_full_size_properties(sd, torch_cuda, oracle):
 
 
 def test_randomised_cross_check(torch_cuda):
-    """tools/fuzz.py: 150 random shapes / strides / offsets / variants over every C-ABI path (FFT, convolution,
+    """tests/fuzz_crosscheck.py: 150 random shapes / strides / offsets / variants over every C-ABI path (FFT, convolution,
     real-input, biquad banks, FIR banks) against numpy and the oracle."""
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz.py"), "7", "150"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_crosscheck.py"), "7", "150"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
