@@ -571,7 +571,10 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
     } else {
-        p->path = (n == (1u << 20) && radix == 2 && precision == SDSP_HIP_F32) ? PATH_FFT1M : PATH_FOUR_STEP;
+        // N = 2^20 f32 runs the tuned two-pass kernels for either radix: a radix-4 DIF stage (fft.h:311-349) is two fused
+        // radix-2 stages, so the 10 + 10 radix-2 stages of fft1m.hip are the same dataflow as ten radix-4 stages (as for
+        // N = 16384 in fft_big.hip); variants >= 8 of such a plan still run genuine radix-4 stages (coverage kernel)
+        p->path = (n == (1u << 20) && precision == SDSP_HIP_F32) ? PATH_FFT1M : PATH_FOUR_STEP;
         const uint32_t k = sdsp_hip_log2(n);
         if (radix == 2) {
             p->n1 = 1u << ((k + 1) / 2);
@@ -604,7 +607,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
         }
     }
-    if (!rc && p->path == PATH_FOUR_STEP && precision == SDSP_HIP_F32 && n >= (1u << 16) && n <= (1u << 19)) {
+    if (!rc && p->path == PATH_FOUR_STEP && precision == SDSP_HIP_F32 && n >= (1u << 16) && n <= (1u << 23)) {
         const uint32_t n2 = n / 16;
         const int sub_radix = (radix == 4 && sdsp_hip_is_power_of_4(n2)) ? 4 : 2;
         rc = sdsp_hip_fft_plan_create(&p->mid_rows, n2, sub_radix, direction, precision, p->ws_batch * 16, device);
@@ -818,7 +821,12 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
                      !p->real_mode && fft_big_supports(p->n, p->radix);
     const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0;
-    info->hbm_passes = mid ? 3 : ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
+    info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
+    if (mid) { // column step + the rows' own passes + untwist
+        sdsp_hip_fft_plan_info rows;
+        sdsp_hip_fft_plan_get_info(p->mid_rows, &rows);
+        info->hbm_passes = 2 + rows.hbm_passes;
+    }
     info->algorithmic_bytes = 2ull * p->n * esize(p->precision); // real plans: n complex = n_real floats, same bytes
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;

@@ -1,4 +1,5 @@
-// fft_mid.hip -- the two streaming passes of the three-pass schedule for N = 2^16 .. 2^19, f32, on gfx950.
+// fft_mid.hip -- the two streaming passes of the three-pass schedule for N = 2^16 .. 2^23 (other than 2^20), f32,
+// on gfx950.  (Above 2^19 the schedule nests: the rows are three-pass plans themselves.)
 //
 // These sizes exceed what one workgroup can hold, and the general four-step through the coverage kernel
 // reaches only 7-15 % of HBM peak.  With N = 16 x N2 (N2 = 4096 .. 32768, i.e. a size one of the tuned
