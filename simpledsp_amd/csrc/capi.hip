@@ -367,11 +367,11 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         while (done < batch) {
             const uint64_t nb = std::min<uint64_t>(p->ws_batch, batch - done);
             char *d = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
-            if (int rc = launch_fft_mid_cols(d, p->workspace, p->tw1024, n2, nb, rev, stream))
+            if (int rc = launch_fft_mid_cols(p->precision, d, p->workspace, p->tw1024, n2, nb, rev, stream))
                 return rc;
             if (int rc = fft_exec_device(p->mid_rows, p->workspace, nb * 16, stream))
                 return rc;
-            if (int rc = launch_fft_mid_untwist(p->workspace, d, n2, nb, stream))
+            if (int rc = launch_fft_mid_untwist(p->precision, p->workspace, d, n2, nb, stream))
                 return rc;
             done += nb;
         }
@@ -607,7 +607,11 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
         }
     }
-    if (!rc && p->path == PATH_FOUR_STEP && precision == SDSP_HIP_F32 && n >= (1u << 16) && n <= (1u << 23)) {
+    // three-pass schedule (fft_mid.hip): f32 N = 2^16 .. 2^23 (2^20 is PATH_FFT1M); f64 N = 2^14 .. 2^21 -- the rows
+    // then land on the f64 register-pass family (N <= 8192) or, nested, on another three-pass plan
+    if (!rc && p->path == PATH_FOUR_STEP &&
+        ((precision == SDSP_HIP_F32 && n >= (1u << 16) && n <= (1u << 23)) ||
+         (precision == SDSP_HIP_F64 && n >= (1u << 14) && n <= (1u << 21)))) {
         const uint32_t n2 = n / 16;
         const int sub_radix = (radix == 4 && sdsp_hip_is_power_of_4(n2)) ? 4 : 2;
         rc = sdsp_hip_fft_plan_create(&p->mid_rows, n2, sub_radix, direction, precision, p->ws_batch * 16, device);

@@ -106,10 +106,98 @@ __global__ __launch_bounds__(256) void sdsp_fft_untwist16(const float2 *__restri
         __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(dst + e));
     }
 }
+// ---- the same two passes in double (the reference's own precision): one column per lane (a complex double is
+// already 16 bytes), four series terms for the fine twiddle factor (t^8/8! < 1e-21 at t < 2 pi / 1024)
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+template <bool REV>
+__global__ __launch_bounds__(256) void sdsp_fft_col16_f64_kernel(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                                 const double2 *__restrict__ tw1024, uint32_t n2, double scale,
+                                                                 uint32_t fine_bits, double fine_step)
+{
+    __shared__ double2 w1k[1024];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        w1k[threadIdx.x + 256 * i] = tw1024[threadIdx.x + 256 * i];
+    __syncthreads();
+    auto twiddle = [&](uint32_t m) {
+        const double th = (double)(m & ((1u << fine_bits) - 1)) * fine_step;
+        const double t2 = th * th;
+        const double cs = 1.0 - t2 * (0.5 - t2 * (1.0 / 24 - t2 * (1.0 / 720)));
+        const double sn = th * (1.0 - t2 * (1.0 / 6 - t2 * (1.0 / 120 - t2 * (1.0 / 5040))));
+        return passes::cmul(w1k[m >> fine_bits], double2{ cs, REV ? sn : -sn });
+    };
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; // over transforms x columns (exact grid)
+    const uint64_t xform = gid / n2;
+    const uint32_t c = (uint32_t)(gid % n2);
+    const uint64_t base = xform * 16ull * n2 + c;
+    double2 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(in + base + (uint64_t)k * n2));
+        x[k] = double2{ v.x, v.y };
+    }
+    const double2 none[4] = {};
+    passes::r2_pass<REV, false, 0>::run(x, none);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t k1 = __brev((uint32_t)k) >> 28;
+        double2 a = x[k];
+        if (k1 != 0)
+            a = passes::cmul(a, twiddle(c * k1));
+        if constexpr (REV) {
+            a.x *= scale;
+            a.y *= scale;
+        }
+        out[base + (uint64_t)k1 * n2] = a;
+    }
+}
+
+constexpr int kPitch64 = 129; // double2 elements per LDS row
+__global__ __launch_bounds__(128) void sdsp_fft_untwist16_f64(const double2 *__restrict__ in, double2 *__restrict__ out, uint32_t n2)
+{
+    __shared__ double2 tile[16 * kPitch64];
+    const uint32_t t = threadIdx.x;
+    const uint32_t blocks_per_xform = n2 / 128;
+    const uint64_t xform = blockIdx.x / blocks_per_xform;
+    const uint32_t k2_0 = (blockIdx.x % blocks_per_xform) * 128;
+    const double2 *src = in + xform * 16ull * n2 + k2_0 + t;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        tile[r * kPitch64 + t] = src[(uint64_t)r * n2];
+    __syncthreads();
+    double2 *dst = out + xform * 16ull * n2 + (uint64_t)k2_0 * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t e = t + 128 * j; // output element within the 2048 of this workgroup
+        const double2 a = tile[(e & 15) * kPitch64 + (e >> 4)];
+        const v2d_t v = { a.x, a.y };
+        __builtin_nontemporal_store(v, reinterpret_cast<v2d_t *>(dst + e));
+    }
+}
 } // namespace
 
-int launch_fft_mid_cols(const void *in, void *out, const void *tw /* W_1024^j */, uint32_t n2, uint64_t batch, int reverse, void *stream)
+int launch_fft_mid_cols(int precision, const void *in, void *out, const void *tw /* W_1024^j */, uint32_t n2, uint64_t batch,
+                        int reverse, void *stream)
 {
+    if (precision == SDSP_HIP_F64) {
+        const uint64_t blocks64 = batch * n2 / 256;
+        if (blocks64 == 0 || blocks64 > 0x7fffffffull)
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+        hipStream_t s64 = reinterpret_cast<hipStream_t>(stream);
+        const uint32_t fb = sdsp_hip_log2(n2) + 4 - 10;
+        const double step = 6.283185307179586476925 / (double)(16ull * n2);
+        const double2 *i64 = reinterpret_cast<const double2 *>(in);
+        double2 *o64 = reinterpret_cast<double2 *>(out);
+        const double2 *w64 = reinterpret_cast<const double2 *>(tw);
+        if (reverse)
+            hipLaunchKernelGGL(sdsp_fft_col16_f64_kernel<true>, dim3((uint32_t)blocks64), dim3(256), 0, s64, i64, o64, w64, n2, 1.0 / 16.0, fb, step);
+        else
+            hipLaunchKernelGGL(sdsp_fft_col16_f64_kernel<false>, dim3((uint32_t)blocks64), dim3(256), 0, s64, i64, o64, w64, n2, 1.0, fb, step);
+        hipError_t e64 = hipGetLastError();
+        if (e64 != hipSuccess)
+            return fail(SDSP_HIP_ERR_HIP, std::string("fft_mid cols launch: ") + hipGetErrorString(e64));
+        return SDSP_HIP_OK;
+    }
     const uint64_t threads = batch * (n2 / 2);
     const uint64_t blocks = threads / 256; // n2 >= 4096: exact
     if (blocks == 0 || blocks > 0x7fffffffull)
@@ -132,8 +220,19 @@ int launch_fft_mid_cols(const void *in, void *out, const void *tw /* W_1024^j */
     return SDSP_HIP_OK;
 }
 
-int launch_fft_mid_untwist(const void *in, void *out, uint32_t n2, uint64_t batch, void *stream)
+int launch_fft_mid_untwist(int precision, const void *in, void *out, uint32_t n2, uint64_t batch, void *stream)
 {
+    if (precision == SDSP_HIP_F64) {
+        const uint64_t blocks64 = batch * (n2 / 128);
+        if (blocks64 == 0 || blocks64 > 0x7fffffffull)
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+        hipLaunchKernelGGL(sdsp_fft_untwist16_f64, dim3((uint32_t)blocks64), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(out), n2);
+        hipError_t e64 = hipGetLastError();
+        if (e64 != hipSuccess)
+            return fail(SDSP_HIP_ERR_HIP, std::string("fft_mid untwist launch: ") + hipGetErrorString(e64));
+        return SDSP_HIP_OK;
+    }
     const uint64_t blocks = batch * (n2 / 256);
     if (blocks == 0 || blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");

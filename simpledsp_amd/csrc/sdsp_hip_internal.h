@@ -93,8 +93,9 @@ bool fft_big_supports(uint32_t n, int radix);
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 
 // N = 2^16 .. 2^19, f32: the two streaming passes around 16 x batch row transforms (fft_mid.hip)
-int launch_fft_mid_cols(const void *in, void *out, const void *tw, uint32_t n2, uint64_t batch, int reverse, void *stream);
-int launch_fft_mid_untwist(const void *in, void *out, uint32_t n2, uint64_t batch, void *stream);
+int launch_fft_mid_cols(int precision, const void *in, void *out, const void *tw, uint32_t n2, uint64_t batch, int reverse,
+                        void *stream);
+int launch_fft_mid_untwist(int precision, const void *in, void *out, uint32_t n2, uint64_t batch, void *stream);
 
 // fast path: batched n = 2^20, radix 2, f32 (BASELINE config 3), one chunk of transforms
 struct fft1m_args {

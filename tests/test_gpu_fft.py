@@ -240,6 +240,28 @@ def test_three_pass_mid_sizes(sd, torch_cuda, oracle, n, radix, batch):
         assert rel_max_err(d2.cpu().numpy(), want) < TOL32
 
 
+@pytest.mark.parametrize("n,radix,batch", [(1 << 14, 2, 5), (1 << 14, 4, 3), (1 << 15, 2, 3), (1 << 16, 4, 2), (1 << 18, 2, 2)])
+def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
+    """The three-pass schedule in double (N = 2^14 .. 2^21): rows on the f64 register-pass family, nested from 2^18."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n * 3 + radix)
+    x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        want = oracle.fft(x, radix, rev)
+        plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=2)
+        assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
+        assert plan.info.hbm_passes == (3 if n < (1 << 18) else 5)
+        d = torch.from_numpy(x).cuda()
+        plan.exec(d)
+        torch.cuda.synchronize()
+        assert rel_max_err(d.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
+        plan.set_variant(1)  # the general four-step through the coverage kernel
+        d2 = torch.from_numpy(x).cuda()
+        plan.exec(d2)
+        torch.cuda.synchronize()
+        assert rel_max_err(d2.cpu().numpy(), want) < _tol64(n)
+
+
 @pytest.mark.parametrize("n,radix,batch", [(1 << 15, 2, 3), (1 << 16, 4, 2), (1 << 18, 2, 2), (1 << 20, 2, 2), (1 << 20, 4, 1)])
 def test_four_step_large_transforms(sd, torch_cuda, oracle, n, radix, batch):
     # sizes beyond LDS: two HBM passes.  The reference itself cannot be compiled for these
