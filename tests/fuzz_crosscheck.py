@@ -25,11 +25,11 @@ for case in range(cases):
     kind = rng.choice(["fft", "fft", "iir", "fir", "conv", "rfft"])
     try:
         if kind in ("fft", "conv", "rfft"):
-            log2n = int(rng.integers(1, 18)) if kind == "fft" else int(rng.integers(4, 14))
+            log2n = int(rng.integers(1, 22)) if kind == "fft" else int(rng.integers(4, 14))  # up to 2^21: nested three-pass plans
             n = 1 << log2n
             radix = 4 if (log2n % 2 == 0 and rng.random() < 0.5) else 2
-            f64 = kind == "fft" and rng.random() < 0.3 and n <= (1 << 16)
-            batch = int(rng.integers(1, max(2, min(300, (1 << 18) // n))))
+            f64 = kind == "fft" and rng.random() < 0.3 and n <= (1 << 18)
+            batch = int(rng.integers(1, max(3, min(300, (1 << 18) // n))))
             rev = bool(rng.integers(0, 2))
             cdt = np.complex128 if f64 else np.complex64
             tol = (8 * n * 2.3e-16) if f64 else 1e-6
