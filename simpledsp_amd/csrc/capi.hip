@@ -308,7 +308,10 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         // chunk i (HBM writes) runs on an internal stream; events order the hand-offs.
         static const uint64_t chunk_of[8] = { 32, 16, 16, 8, 24, 12, 8, 4 };
         static const bool overlap_of[8] = { false, true, false, true, false, true, false, true };
-        const bool overlap = overlap_of[p->variant];
+        // the two-stream variants need two workspace halves: a plan created for a single transform has one, and
+        // runs them serially (found by the randomised cross-check: half 1 used to start past the end of a
+        // one-transform workspace)
+        const bool overlap = overlap_of[p->variant] && p->ws_batch >= 2;
         const uint64_t cap = overlap ? p->ws_batch / 2 : p->ws_batch;
         const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk_of[p->variant], cap));
         const uint64_t N = 1ull << 20;

@@ -314,6 +314,25 @@ def test_large_single_pass_kernel(sd, torch_cuda, oracle, n, batch):
     assert rel_max_err(d.cpu().numpy(), x) < TOL32
 
 
+def test_fft1m_two_stream_variants_with_a_one_transform_workspace(sd, torch_cuda, oracle):
+    """Regression (found by tests/fuzz_crosscheck.py, seed 31): the overlapped variants split the workspace in two
+    halves; a plan created with max_batch = 1 has a single-transform workspace and must run them serially."""
+    rng = np.random.default_rng(31)
+    n = 1 << 20
+    x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+    want = np.fft.fft(x.astype(np.complex128), axis=-1)
+    for radix in (2, 4):
+        for variant in (1, 3, 5, 7):
+            plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=1)
+            plan.set_variant(variant)
+            d = torch_cuda.from_numpy(x).cuda()
+            guard = torch_cuda.full((1 << 16,), 7.0 + 3.0j, dtype=torch_cuda.complex64, device="cuda")
+            plan.exec(d)
+            torch_cuda.cuda.synchronize()
+            assert rel_max_err(d.cpu().numpy(), want) < TOL32, (radix, variant)
+            assert bool((guard == 7.0 + 3.0j).all())
+
+
 def test_fft1m_chunking_and_two_stream_variants_agree(sd, torch_cuda, oracle):
     # N = 2^20 radix-2: serial chunks, two-stream overlapped chunks (double-buffered workspace) and the
     # coverage kernel compute the same transform; batch 37 is ragged against every chunk size
