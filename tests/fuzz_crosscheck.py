@@ -37,8 +37,8 @@ for case in range(cases):
             if kind == "fft":
                 plan = sd.FftPlan(n, radix, sd.reverse_fft if rev else sd.forward_fft, sd.F64 if f64 else sd.F32,
                                   max_batch=int(rng.integers(1, batch + 1)))
-                if rng.random() < 0.3:
-                    plan.set_variant(int(rng.integers(0, 4)))
+                if rng.random() < 0.3:  # every kernel variant a plan of this shape can reach (out-of-range ones fall back)
+                    plan.set_variant(int(rng.integers(0, 24)) if (n, radix, f64) == (4096, 4, False) else int(rng.integers(0, 10)))
                 d = torch.from_numpy(x).cuda()
                 plan.exec(d)
                 torch.cuda.synchronize()
@@ -90,14 +90,25 @@ for case in range(cases):
             bank.set_variant(int(rng.integers(0, 7)))
             dt = np.float64 if f64 else np.float32
             x = rng.standard_normal((channels, samples + pad)).astype(dt)
-            d = torch.from_numpy(x).cuda()
             cut = int(rng.integers(0, samples + 1))
-            if cut:
-                bank.process(d, samples=cut, offset=off)
-            if samples - cut:
-                bank.process(d, samples=samples - cut, offset=off + cut)
-            torch.cuda.synchronize()
-            got = d.cpu().numpy()
+            wire = rng.random() < 0.3 and (f64 or channels % 2 == 0)  # sample-major "wire" layout
+            if wire:
+                bank.set_variant(int(rng.integers(0, 5)))
+                dw = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()  # (samples + pad, channels)
+                if cut:
+                    bank.process_interleaved(dw, samples=cut, offset=off)
+                if samples - cut:
+                    bank.process_interleaved(dw, samples=samples - cut, offset=off + cut)
+                torch.cuda.synchronize()
+                got = dw.cpu().numpy().T
+            else:
+                d = torch.from_numpy(x).cuda()
+                if cut:
+                    bank.process(d, samples=cut, offset=off)
+                if samples - cut:
+                    bank.process(d, samples=samples - cut, offset=off + cut)
+                torch.cuda.synchronize()
+                got = d.cpu().numpy()
             err = 0.0
             for c in sorted({0, channels - 1, int(rng.integers(0, channels))}):
                 fo = o.iir(m)
@@ -111,7 +122,7 @@ for case in range(cases):
                 if not np.array_equal(got[c, :off], x[c, :off]) or not np.array_equal(got[c, off + samples:], x[c, off + samples:]):
                     err = 9.0
             tol = 0.5 if f64 else 3e-6  # 8 sections accumulate more rounding than the 4 of the BASELINE filter (1e-6)
-            desc = f"iir m={m} {'f64' if f64 else 'f32'} ch={channels} n={samples} pad={pad} off={off} type={ftype} kind={spec_kind} var={bank._variant}"
+            desc = f"iir{' wire' if wire else ''} m={m} {'f64' if f64 else 'f32'} ch={channels} n={samples} pad={pad} off={off} type={ftype} kind={spec_kind} var={bank._variant}"
         else:
             taps = int(rng.integers(1, 200))
             f64 = rng.random() < 0.5
