@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_il]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_lp|iir_il]
     python bench.py --workload fft --n 8192 --radix 2 [--precision f64]     (any covered size; not a BASELINE config)
     python bench.py --workload fir --taps 32                                  (FIR bank; not a BASELINE config)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -14,6 +14,12 @@ in-place data stays finite and random-like for any K (same kernel template; the 
 reference's 1/N scale, fft.h:128-132).  For N > 1 every rank owns a shard of the same size on its
 own GPU (weak scaling; the transforms are independent, so there is no data-path collective --
 torch.distributed is used for the start/stop barrier and the max-over-ranks time only).
+
+At N = 1 the default run then measures the other single-GPU BASELINE configs with the same K / W and appends
+them to the SAME JSON line as `"other_configs": [{config, metric, value, unit, dtype, ms_per_step, roofline, cpu_baseline}]`:
+configs[2] (N = 2^20, batch 256), configs[3] (biquad bank 1M x 4096: f32, f64, and the numerator-folded LP class,
+testIIR.cpp:465-494) and one configs[4] shard (262144 transforms = 8 GiB) on this one GPU.  `--no-other-configs`
+skips them.  With N > 1 the per-GPU shard is configs[4]'s 262144 transforms.
 
 `roofline.achieved` = algorithmic bytes per launch (each element read once + written
 once) / average launch duration measured with HIP events on the launch stream inside this run.
@@ -41,7 +47,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_il", "fft", "fir"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_il", "fft", "fir"])
     ap.add_argument("--n", type=int, default=1024, help="--workload fft: transform size")
     ap.add_argument("--radix", type=int, default=2, help="--workload fft: 2 or 4")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / fir")
@@ -50,6 +56,8 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-other-configs", action="store_true", help="headline workload only")
+    ap.add_argument("--other-cpu-seconds", type=float, default=3.0, help="CPU leg of each other_configs entry")
     return ap.parse_args()
 
 
@@ -57,7 +65,9 @@ def parse_args():
 # workloads: each returns (step_fn, units_per_step, algorithmic_bytes_per_unit, describe dict)
 
 def make_fft4096(sd, torch, dev, args):
-    batch = args.batch_per_gpu or 65536
+    # N = 1: configs[1] (65536 transforms, 2 GiB).  N > 1: configs[4] -- 2M transforms over 8 GPUs = 262144 (8 GiB) per
+    # GPU, the same shard at every N > 1 (weak scaling; per-transform throughput does not depend on the batch above ~10k)
+    batch = args.batch_per_gpu or (262144 if args.world > 1 else 65536)
     g = torch.Generator(device=dev).manual_seed(0x5D5B + dev.index)
     x = torch.view_as_complex(torch.randn((batch, 4096, 2), generator=g, device=dev, dtype=torch.float32))
     fwd = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32, max_batch=batch, device=dev.index)
@@ -72,8 +82,9 @@ def make_fft4096(sd, torch, dev, args):
         state["i"] += 1
 
     info = fwd.info
+    which = "configs[1]" if batch == 65536 else "configs[4] shard (2M transforms / 8 GPUs)" if batch == 262144 else "configs[1] shape"
     desc = {
-        "workload": "BASELINE configs[1]: batched N=4096 radix-4 complex FFT, in place, fp32",
+        "workload": f"BASELINE {which}: batched N=4096 radix-4 complex FFT, in place, fp32",
         "n": 4096, "radix": 4, "batch_per_gpu": batch,
         "direction": "forward/reverse alternating (keeps the in-place data finite)",
         "kernel": info.kernel.decode(), "hbm_passes": info.hbm_passes,
@@ -158,13 +169,14 @@ def make_fir(sd, torch, dev, args):
             args.precision, (bank, x))
 
 
-def make_iir(sd, torch, dev, args, f64=False, interleaved=False):
+def make_iir(sd, torch, dev, args, f64=False, interleaved=False, lp_class=False):
     channels = args.batch_per_gpu or (1 << 20)
     samples = 4096
     dt = torch.float64 if f64 else torch.float32
     g = torch.Generator(device=dev).manual_seed(0x5D5B + 2 + dev.index)
     x = torch.randn((samples, channels) if interleaved else (channels, samples), generator=g, device=dev, dtype=dt)
-    bank = sd.casc_2o_iir(4, channels, sd.F64 if f64 else sd.F32, sd.IIR_GENERIC, device=dev.index)
+    # casc_2o_iir<4> (testIIR.cpp:465-487) or the numerator-folded casc_2o_iir_lp<4> (:489-494)
+    bank = sd.casc_2o_iir(4, channels, sd.F64 if f64 else sd.F32, sd.IIR_LP if lp_class else sd.IIR_GENERIC, device=dev.index)
     bank.set_lp_coeff(10e3, 100e3)  # testIIR.cpp:469-474
     if args.variant >= 0:
         bank.set_variant(args.variant)
@@ -178,13 +190,15 @@ def make_iir(sd, torch, dev, args, f64=False, interleaved=False):
 
     bank.reset()
     desc = {
-        "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place",
-        "sections": 4, "channels_per_gpu": channels, "samples": samples,
+        "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place"
+                    + (" -- casc_2o_iir_lp<4> (numerator-folded class)" if lp_class else " -- casc_2o_iir<4>"),
+        "sections": 4, "class": "casc_2o_iir_lp" if lp_class else "casc_2o_iir", "channels_per_gpu": channels, "samples": samples,
         "kernel": "sdsp_iir_interleaved_kernel" if interleaved else "sdsp_iir_supertile_kernel",
         "layout": "sample-major [sample][channel] (SURVEY 8f-2)" if interleaved else "channel-major (BASELINE)",
     }
     unit_bytes = 16 if f64 else 8
-    return step, channels * samples, unit_bytes, desc, "IIR samples/sec (4 cascaded biquads, LP)", "samples/s", "f64" if f64 else "f32", (bank, x)
+    metric = "IIR samples/sec (4 cascaded biquads, LP" + (", casc_2o_iir_lp class)" if lp_class else ")")
+    return step, channels * samples, unit_bytes, desc, metric, "samples/s", "f64" if f64 else "f32", (bank, x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -201,9 +215,9 @@ def cpu_baseline(workload: str, seconds: float):
     be = Reference() if kind == "reference" else Oracle()
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
     rng = np.random.default_rng(0x5D5B)
-    deadline = time.perf_counter() + seconds
     counts = [0] * cores
 
+    deadline = None  # set right before the threads start (plan creation for N = 2^20 takes seconds)
     if workload.startswith("fft"):
         n, radix, per = (4096, 4, 64) if workload == "fft4096" else (1 << 20, 2, 1)
         if workload == "fft1m":
@@ -223,8 +237,9 @@ def cpu_baseline(workload: str, seconds: float):
         sample = f"N={n} radix-{radix} complex128 forward, {per} transforms per pass per thread, ~{seconds:.0f} s wall"
     else:
         per = 16
+        ckind = 1 if workload == "iir_lp" else 0  # casc_2o_iir_lp<4> (testIIR.cpp:489-494) / casc_2o_iir<4> (:465-487)
         if kind == "reference":
-            filt = [be.iir(4, 0) for _ in range(cores)]
+            filt = [be.iir(4, ckind) for _ in range(cores)]
         else:
             filt = [be.iir(4) for _ in range(cores)]
         for f in filt:
@@ -235,12 +250,14 @@ def cpu_baseline(workload: str, seconds: float):
             a = bufs[i].copy()
             while time.perf_counter() < deadline:
                 for r in range(per):
-                    filt[i].process_inplace(a[r])
+                    filt[i].process_inplace(a[r], ckind)
                 counts[i] += per * 4096
         unit = "samples/s"
-        sample = f"casc_2o_iir<4> LP, 4096-sample blocks (testIIR.cpp:482-487), float64, ~{seconds:.0f} s wall"
+        cls = "casc_2o_iir_lp<4>" if ckind else "casc_2o_iir<4> LP"
+        sample = f"{cls}, 4096-sample blocks (testIIR.cpp:{'489-494' if ckind else '482-487'}), float64, ~{seconds:.0f} s wall"
 
     t0 = time.perf_counter()
+    deadline = t0 + seconds
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     for t in th:
         t.start()
@@ -265,6 +282,61 @@ def read_traffic(kernels: str):
         return None
 
 
+WORKLOADS = {
+    "fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
+    "iir64": lambda *a: make_iir(*a, f64=True),
+    "iir_lp": lambda *a: make_iir(*a, lp_class=True),
+    "iir_il": lambda *a: make_iir(*a, interleaved=True), "fft": make_fft, "fir": make_fir,
+}
+
+
+def measure(name, sd, torch, dev, args, dist, steps, warmup):
+    """One workload: setup, wake-up, W untimed + exactly K timed steps (barrier + synchronize on both sides, max over
+    ranks), HIP events on the launch stream for the kernel time.  Returns the fields of one result object."""
+    from simpledsp_amd.dist import timed_steps
+    step, units, unit_bytes, desc, metric, unit, dtype, keep = WORKLOADS[name](sd, torch, dev, args)
+
+    # Setup, not measurement: wake the device up.  The first ~20 back-to-back launches after idle run
+    # up to 20 % slower (power/clock transient, profiles/r01_fft4096_summary.md); ~150 ms of untimed
+    # work here puts the W warmup steps and the K timed steps in steady state whatever W is.
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.15:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize(dev)
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_calls = {"i": 0}
+
+    def timed_step():
+        if n_calls["i"] == warmup:
+            ev0.record()
+        step()
+        n_calls["i"] += 1
+        if n_calls["i"] == warmup + steps:
+            ev1.record()
+
+    wall = timed_steps(timed_step, steps, warmup, lambda: torch.cuda.synchronize(dev), dist, dev)
+    kern_ms = ev0.elapsed_time(ev1) / max(1, steps)
+    world = args.world
+    achieved = units * unit_bytes / (kern_ms * 1e-3) / 1e9
+    res = {
+        "metric": metric, "value": units * world * steps / wall, "unit": unit,
+        "ms_per_step": wall / steps * 1e3, "dtype": dtype,
+        "config": {**desc, "parallelism": f"batch-shard x{world}, no collective"},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"]),
+            "traffic_source": "committed PMC summary profiles/traffic.json (separate rocprofv3 --pmc passes), not this run",
+            "kernel": desc["kernel"], "avg_launch_ms": kern_ms,
+            "algorithmic_bytes_per_launch": units * unit_bytes,
+        },
+    }
+    del keep, step
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse_args()
     # stdout carries exactly ONE line, the JSON: libraries that chat on fd 1 (RCCL prints a version banner
@@ -278,6 +350,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    args.world = world
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
@@ -291,60 +364,44 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    mk = {"fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
-          "iir64": lambda *a: make_iir(*a, f64=True),
-          "iir_il": lambda *a: make_iir(*a, interleaved=True), "fft": make_fft, "fir": make_fir}[args.workload]
-    step, units, unit_bytes, desc, metric, unit, dtype, keep = mk(sd, torch, dev, args)
+    head = measure(args.workload, sd, torch, dev, args, dist, args.steps, args.warmup)
 
-    # Setup, not measurement: wake the device up.  The first ~20 back-to-back launches after idle run
-    # up to 20 % slower (power/clock transient, profiles/r01_fft4096_summary.md); ~150 ms of untimed
-    # work here puts the W warmup steps and the K timed steps in steady state whatever W is.
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < 0.15:
-        for _ in range(4):
-            step()
-        torch.cuda.synchronize(dev)
-
-    # W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides,
-    # max over ranks (simpledsp_amd/dist.py); HIP events on the launch stream give the kernel time.
-    from simpledsp_amd.dist import timed_steps
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n_calls = {"i": 0}
-
-    def timed_step():
-        if n_calls["i"] == args.warmup:
-            ev0.record()
-        step()
-        n_calls["i"] += 1
-        if n_calls["i"] == args.warmup + args.steps:
-            ev1.record()
-
-    wall = timed_steps(timed_step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), dist, dev)
-    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)
+    # the other single-GPU BASELINE configs, same K / W, appended to the same line (N = 1, default workload only)
+    others = []
+    if world == 1 and args.workload == "fft4096" and not args.no_other_configs and not args.batch_per_gpu and args.variant < 0:
+        plan = [("fft1m", 0), ("iir", 0), ("iir64", 0), ("iir_lp", 0), ("fft4096", 262144)]
+        for name, batch in plan:
+            args.batch_per_gpu = batch
+            r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
+            r["steps"], r["warmup"] = args.steps, args.warmup
+            others.append((name, r))
+        args.batch_per_gpu = 0
 
     if rank == 0:
-        total_units = units * world * args.steps
-        value = total_units / wall
-        achieved = units * unit_bytes / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {**desc, "parallelism": f"batch-shard x{world}, no collective"},
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"]),
-                "kernel": desc["kernel"], "avg_launch_ms": kern_ms,
-                "algorithmic_bytes_per_launch": units * unit_bytes,
-            },
+            "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": head["config"], "roofline": head["roofline"],
         }
         # the extra workloads (--workload fft / fir) are not BASELINE configs: no CPU leg for them
         if world == 1 and not args.no_cpu_baseline and args.workload not in ("fft", "fir"):
-            del keep
-            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if out["cpu_baseline"]["value"]:
-                out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                out["cpu_baseline"]["gpu_over_cpu"] = head["value"] / out["cpu_baseline"]["value"]
+        if others:
+            out["other_configs"] = []
+            cpu_cache = {}
+            for name, r in others:
+                # the cfg-5 shard shares the headline's CPU leg; iir64 shares iir's (the reference computes in double anyway)
+                if not args.no_cpu_baseline and name != "fft4096":
+                    key = "iir" if name == "iir64" else name
+                    if key not in cpu_cache:
+                        cpu_cache[key] = cpu_baseline(key, args.other_cpu_seconds)
+                    r["cpu_baseline"] = dict(cpu_cache[key])
+                    if r["cpu_baseline"]["value"]:
+                        r["cpu_baseline"]["gpu_over_cpu"] = r["value"] / r["cpu_baseline"]["value"]
+                out["other_configs"].append(r)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()

@@ -34,42 +34,106 @@ namespace detail
 template <size_t m_t> using mem_array = std::array<std::array<double, 3>, m_t + 1>;
 template <size_t m_t> using coeff3_array = std::array<std::array<double, 3>, m_t>;
 
-// Run `n` samples of ONE stream through the f64 bank kernel.  The reference keeps its history in a
+// Device-side context of ONE filter object: the plan and a staging buffer that survive between process() calls, so
+// that a caller streaming short blocks (testIIR.cpp:61-75 feeds 32 samples at a time) pays one upload, one launch
+// and one download per block instead of a plan build and two hipMalloc/hipFree pairs.  It is a cache, not state:
+// copying a filter copies coefficients and history (the reference's value semantics, testIIR.cpp:48) and starts
+// the copy with an empty context; a new design drops the plan.
+class stream_ctx {
+public:
+    stream_ctx() = default;
+    stream_ctx(const stream_ctx &) noexcept {}
+    stream_ctx &operator=(const stream_ctx &) noexcept
+    {
+        drop_plan(); // the design may differ after an assignment
+        return *this;
+    }
+    ~stream_ctx()
+    {
+        drop_plan();
+        if (m_dev)
+            sdsp_hip_free(m_dev, 0);
+    }
+    void drop_plan() noexcept
+    {
+        if (m_plan)
+            sdsp_hip_iir_plan_destroy(m_plan);
+        m_plan = nullptr;
+    }
+    sdsp_hip_iir_plan *&plan() noexcept { return m_plan; }
+    // device buffer of at least `doubles` doubles (grow-only)
+    double *device(std::size_t doubles)
+    {
+        if (doubles > m_cap) {
+            if (m_dev)
+                sdsp_hip_free(m_dev, 0);
+            m_dev = nullptr;
+            m_cap = 0;
+            std::size_t want = 256;
+            while (want < doubles)
+                want *= 2;
+            void *d = nullptr;
+            check(sdsp_hip_malloc(&d, want * sizeof(double), 0));
+            m_dev = static_cast<double *>(d);
+            m_cap = want;
+        }
+        return m_dev;
+    }
+    std::vector<double> &host() noexcept { return m_host; }
+
+private:
+    sdsp_hip_iir_plan *m_plan{ nullptr };
+    double *m_dev{ nullptr };
+    std::size_t m_cap{ 0 };
+    std::vector<double> m_host; // [state | samples] staging image
+};
+
+// Run the samples of [begin, end) of ONE stream through the f64 bank kernel.  The reference keeps its history in a
 // 3-deep ring indexed by m_pos (casc_2o_iir.h:11-15, :54-60, :73-75); the device layout is the same
-// ring rotated so that slot `age` is the value age+1 samples ago (sdsp_hip.h).
+// ring rotated so that slot `age` is the value age+1 samples ago (sdsp_hip.h).  Like the reference's process(),
+// this takes any iterator pair with ++, * and != over doubles (std::deque, std::list ...): the samples are staged
+// through one contiguous [state | samples] image, which is also what makes the call one upload and one download.
 template <size_t m_t, typename iter_t>
-void process_single(int kind, double gain, const coeff3_array<m_t> &a, const coeff3_array<m_t> *b, mem_array<m_t> &mem,
-                    int &pos, iter_t begin, iter_t end)
+void process_single(stream_ctx &ctx, int kind, double gain, const coeff3_array<m_t> &a, const coeff3_array<m_t> *b,
+                    mem_array<m_t> &mem, int &pos, iter_t begin, iter_t end)
 {
     using value_t = typename std::iterator_traits<iter_t>::value_type;
     static_assert(std::is_same<value_t, double>::value, "the drop-in classes filter double samples, like the reference");
-    const auto n = static_cast<std::uint64_t>(std::distance(begin, end));
-    if (n == 0)
-        return;
-    double *samples = &*begin; // contiguous storage (std::vector / std::array / pointers)
-
-    std::array<double, 3 * m_t> af{}, bf{};
-    for (size_t j = 0; j < m_t; ++j)
-        for (size_t i = 0; i < 3; ++i) {
-            af[3 * j + i] = a[j][i];
-            bf[3 * j + i] = b ? (*b)[j][i] : 0.0;
-        }
-    std::array<double, 3 * (m_t + 1)> state{};
+    static_assert(m_t <= SDSP_HIP_MAX_SECTIONS, "at most SDSP_HIP_MAX_SECTIONS (16) sections are compiled into libsdsp_hip");
+    constexpr std::size_t kState = 3 * (m_t + 1);
+    std::vector<double> &img = ctx.host();
+    img.resize(kState);
     for (size_t j = 0; j <= m_t; ++j)
         for (int age = 0; age < 3; ++age)
-            state[3 * j + age] = mem[j][static_cast<size_t>((pos + 2 - age + 3) % 3)]; // (pos-1-age) mod 3
+            img[3 * j + static_cast<size_t>(age)] = mem[j][static_cast<size_t>((pos + 2 - age + 3) % 3)]; // (pos-1-age) mod 3
+    for (iter_t it = begin; it != end; ++it)
+        img.push_back(*it);
+    const std::uint64_t n = img.size() - kState;
+    if (n == 0)
+        return;
 
-    sdsp_hip_iir_plan *plan = nullptr;
-    check(sdsp_hip_iir_plan_create(&plan, static_cast<std::uint32_t>(m_t), kind, af.data(), b ? bf.data() : nullptr, gain,
-                                   SDSP_HIP_F64, 0));
-    const int rc = sdsp_hip_iir_process_host(plan, samples, 1, n, n, state.data());
-    sdsp_hip_iir_plan_destroy(plan);
-    check(rc);
+    if (!ctx.plan()) {
+        std::array<double, 3 * m_t> af{}, bf{};
+        for (size_t j = 0; j < m_t; ++j)
+            for (size_t i = 0; i < 3; ++i) {
+                af[3 * j + i] = a[j][i];
+                bf[3 * j + i] = b ? (*b)[j][i] : 0.0;
+            }
+        check(sdsp_hip_iir_plan_create(&ctx.plan(), static_cast<std::uint32_t>(m_t), kind, af.data(), b ? bf.data() : nullptr,
+                                       gain, SDSP_HIP_F64, 0));
+    }
+    double *dev = ctx.device(img.size());
+    check(sdsp_hip_memcpy_h2d(dev, img.data(), img.size() * sizeof(double), 0));
+    check(sdsp_hip_iir_process(ctx.plan(), dev + kState, 1, n, n, dev, nullptr));
+    check(sdsp_hip_memcpy_d2h(img.data(), dev, img.size() * sizeof(double), 0)); // synchronises with the launch
 
+    std::size_t k = kState;
+    for (iter_t it = begin; it != end; ++it)
+        *it = img[k++];
     pos = static_cast<int>((static_cast<std::uint64_t>(pos) + n) % 3);
     for (size_t j = 0; j <= m_t; ++j)
         for (int age = 0; age < 3; ++age)
-            mem[j][static_cast<size_t>((pos + 2 - age + 3) % 3)] = state[3 * j + age];
+            mem[j][static_cast<size_t>((pos + 2 - age + 3) % 3)] = img[3 * j + static_cast<size_t>(age)];
 }
 } // namespace detail
 
@@ -82,6 +146,7 @@ private:
     detail::coeff3_array<m_t> m_b_coeff{};
     detail::coeff3_array<m_t> m_a_coeff{};
     filter_type m_f_type{ filter_type::none };
+    detail::stream_ctx m_ctx; // device-side cache (plan + staging buffer), not part of the filter's value
 
     void store_design(const std::array<double, 3 * m_t> &a, const std::array<double, 3 * m_t> &b, double gain, filter_type t)
     {
@@ -92,6 +157,7 @@ private:
             }
         m_gain = gain;
         m_f_type = t;
+        m_ctx.drop_plan();
     }
 
 public:
@@ -103,11 +169,12 @@ public:
         m_b_coeff = other_filter.m_b_coeff;
         m_a_coeff = other_filter.m_a_coeff;
         m_f_type = other_filter.m_f_type;
+        m_ctx.drop_plan();
     }
 
     template <typename iter_t> void process(iter_t begin, iter_t end)
     {
-        detail::process_single<m_t>(SDSP_HIP_IIR_GENERIC, m_gain, m_a_coeff, &m_b_coeff, m_mem, m_pos, begin, end);
+        detail::process_single<m_t>(m_ctx, SDSP_HIP_IIR_GENERIC, m_gain, m_a_coeff, &m_b_coeff, m_mem, m_pos, begin, end);
     }
 
     void set_bp_coeff(double f0, double fs, double q, double gain_in = 1.0)
@@ -173,10 +240,11 @@ protected:
     double m_gain{ 1.0 };
     detail::mem_array<m_t> m_mem{};
     detail::coeff3_array<m_t> m_a_coeff{};
+    detail::stream_ctx m_ctx; // device-side cache (plan + staging buffer), not part of the filter's value
 
     template <typename iter_t> void process_kind(int kind, iter_t begin, iter_t end)
     {
-        detail::process_single<m_t>(kind, m_gain, m_a_coeff, nullptr, m_mem, m_pos, begin, end);
+        detail::process_single<m_t>(m_ctx, kind, m_gain, m_a_coeff, nullptr, m_mem, m_pos, begin, end);
     }
     void store_design(const std::array<double, 3 * m_t> &a, double gain)
     {
@@ -184,11 +252,13 @@ protected:
             for (size_t i = 0; i < 3; ++i)
                 m_a_coeff[j][i] = a[3 * j + i];
         m_gain = gain;
+        m_ctx.drop_plan();
     }
     void copy_design(const casc_2o_iir_base &o)
     {
         m_gain = o.m_gain;
         m_a_coeff = o.m_a_coeff;
+        m_ctx.drop_plan();
     }
 };
 
@@ -248,8 +318,8 @@ public:
     }
     template <typename iter_t> void process(iter_t begin, iter_t end)
     {
-        detail::process_single<m_t>(SDSP_HIP_IIR_GENERIC, this->m_gain, this->m_a_coeff, &m_b_coeff, this->m_mem, this->m_pos,
-                                    begin, end);
+        detail::process_single<m_t>(this->m_ctx, SDSP_HIP_IIR_GENERIC, this->m_gain, this->m_a_coeff, &m_b_coeff, this->m_mem,
+                                    this->m_pos, begin, end);
     }
     void set_bs_coeff(double f0, double fs, double q, double gain_in = 1.0)
     {

@@ -96,6 +96,19 @@ public:
     constexpr static double Sym90() { return -1.0; }
 };
 
+// trig_array<N> straight from the calculator, no symmetry tricks (reference fft.h:54-65): row i, column j =
+// T::Value(2 pi j / 2^(i+1)).  The reference keeps it beside calc_trigs for comparison; so does this header.
+template <size_t N, class T> trig_array<N> calc_trigs_naive()
+{
+    trig_array<N> trigs{};
+    for (size_t i = 0; i < trigs.size(); ++i) {
+        const double period = static_cast<double>(1u << (i + 1u));
+        for (size_t j = 0; j < N; ++j)
+            trigs[i][j] = T::Value(2 * M_PI * static_cast<double>(j) / period);
+    }
+    return trigs;
+}
+
 // ---- run-time tables ---------------------------------------------------------------------------
 // One row exp(-/+ 2 pi i j / N), j < N -- the only row the GPU kernels keep resident; produced by
 // the same host routine that fills the plans (sdsp_hip_calc_twiddles).

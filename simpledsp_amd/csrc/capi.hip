@@ -17,6 +17,22 @@ int launch_fft1m_pass(const fft1m_args &a, int which, void *stream);
 
 using namespace sdsp_hip;
 
+int sdsp_hip::ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit)
+        return SDSP_HIP_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+    done.fetch_or(bit, std::memory_order_release);
+    return SDSP_HIP_OK;
+}
+
 namespace
 {
 int hip_fail(hipError_t e, const char *what)
@@ -201,23 +217,38 @@ void pick_tile(int precision, uint32_t n, uint32_t want_cols, uint32_t *cols, ui
     *pitch = c > 1 ? c + 1 : 1; // odd pitch: both access orders spread over the banks
 }
 
-int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream)
+// the multi-pass paths' plan-owned workspace, allocated on the first exec that needs it (single-pass default kernels
+// such as fft_big at N = 32768 never do)
+int ensure_workspace(sdsp_hip_fft_plan *p)
+{
+    if (p->workspace || p->workspace_bytes == 0)
+        return SDSP_HIP_OK;
+    hipError_t e = hipMalloc(&p->workspace, p->workspace_bytes);
+    if (e != hipSuccess) {
+        p->workspace = nullptr;
+        return fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
+    }
+    return SDSP_HIP_OK;
+}
+
+// `variant`: the kernel variant to run (normally the plan's; the convolution path overrides it without touching the plan)
+int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream, int variant)
 {
     if (batch == 0 || p->path == PATH_NOOP)
         return SDSP_HIP_OK;
     const bool rev = p->direction == SDSP_HIP_REVERSE;
 
-    if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants()) {
+    if (p->path == PATH_FFT4096 && variant < fft4096_num_variants()) {
         fft4096_args a;
         a.data = data;
         a.tw = p->twt;
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
-        return launch_fft4096_r4_f32(a, p->variant, stream);
+        return launch_fft4096_r4_f32(a, variant, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (p->variant == 0 || p->variant == 3) && p->n == 4096 &&
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (variant == 0 || variant == 3) && p->n == 4096 &&
         p->radix == 2 && !p->real_mode) {
         fft4096_args a;
         a.data = data;
@@ -225,12 +256,12 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
-        a.pair = p->variant == 3; // 3: two consecutive transforms per workgroup
+        a.pair = variant == 3; // 3: two consecutive transforms per workgroup
         return launch_fft4096_r2_f32(a, stream);
     }
 
     // N = 8192 / 16384 / 32768 radix 2 f32: registers-resident single-pass kernel (fft_big.hip)
-    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == 0 &&
         !p->real_mode && fft_big_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
@@ -244,7 +275,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_big_f32(a, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && variant == 0) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;
@@ -258,7 +289,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_reg_f64(a, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant < 3) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant < 3) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;
@@ -267,7 +298,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.batch = batch;
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
-        a.nontemporal = p->variant != 1; // 0 (and 2 at n = 4096 radix 2, where 0 is the tuned kernel)
+        a.nontemporal = variant != 1; // 0 (and 2 at n = 4096 radix 2, where 0 is the tuned kernel)
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
         return launch_fft_reg_f32(a, stream);
@@ -301,7 +332,10 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_tile(p->precision, p->radix, a, tiles, stream);
     }
 
-    if (p->path == PATH_FFT1M && p->variant < 8) {
+    if (int rc = ensure_workspace(p)) // every path below is multi-pass
+        return rc;
+
+    if (p->path == PATH_FFT1M && variant < 8) {
         // Chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache when
         // pass 2 reads them.  variant -> (chunk, overlap).  With overlap the workspace is used as two
         // halves and pass 1 of chunk i+1 (HBM reads) runs on the caller's stream while pass 2 of
@@ -311,9 +345,9 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         // the two-stream variants need two workspace halves: a plan created for a single transform has one, and
         // runs them serially (found by the randomised cross-check: half 1 used to start past the end of a
         // one-transform workspace)
-        const bool overlap = overlap_of[p->variant] && p->ws_batch >= 2;
+        const bool overlap = overlap_of[variant] && p->ws_batch >= 2;
         const uint64_t cap = overlap ? p->ws_batch / 2 : p->ws_batch;
-        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk_of[p->variant], cap));
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk_of[variant], cap));
         const uint64_t N = 1ull << 20;
         auto args_for = [&](uint64_t done, int half) {
             fft1m_args a;
@@ -364,7 +398,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     }
 
     // N = 2^16 .. 2^19, f32: three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel
-    if (p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0) {
+    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == 0) {
         const uint32_t n2 = p->n / 16;
         uint64_t done = 0;
         while (done < batch) {
@@ -372,7 +406,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             char *d = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
             if (int rc = launch_fft_mid_cols(p->precision, d, p->workspace, p->tw1024, n2, nb, rev, stream))
                 return rc;
-            if (int rc = fft_exec_device(p->mid_rows, p->workspace, nb * 16, stream))
+            if (int rc = fft_exec_device(p->mid_rows, p->workspace, nb * 16, stream, p->mid_rows->variant))
                 return rc;
             if (int rc = launch_fft_mid_untwist(p->precision, p->workspace, d, n2, nb, stream))
                 return rc;
@@ -603,12 +637,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
         // the tuned 2^20 path runs chunk by chunk and never needs more than 32 intermediate matrices
         p->ws_batch = p->path == PATH_FFT1M ? std::min<uint64_t>(p->max_batch, 32) : p->max_batch;
-        p->workspace_bytes = p->ws_batch * n * esize(precision);
-        if (!rc) {
-            hipError_t e = hipMalloc(&p->workspace, p->workspace_bytes);
-            if (e != hipSuccess)
-                rc = fail(SDSP_HIP_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
-        }
+        p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
     }
     // three-pass schedule (fft_mid.hip): f32 N = 2^16 .. 2^23 (2^20 is PATH_FFT1M); f64 N = 2^14 .. 2^21 -- the rows
     // then land on the f64 register-pass family (N <= 8192) or, nested, on another three-pass plan
@@ -704,7 +733,7 @@ int sdsp_hip_fft_exec(sdsp_hip_fft_plan *p, void *data, uint64_t batch, void *st
         return fail(SDSP_HIP_ERR_INVALID_ARG, "data must be aligned to one complex element");
     if (int rc = use_device(p->device))
         return rc;
-    return fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream));
+    return fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream), p->variant);
 }
 
 int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *p, void *host_data, uint64_t batch)
@@ -728,7 +757,7 @@ int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *p, void *host_data, uint64_t batch
         p->host_stage_bytes = bytes;
     }
     HIP_TRY(hipMemcpy(p->host_stage, host_data, bytes, hipMemcpyHostToDevice));
-    if (int rc = fft_exec_device(p, p->host_stage, batch, nullptr))
+    if (int rc = fft_exec_device(p, p->host_stage, batch, nullptr, p->variant))
         return rc;
     HIP_TRY(hipMemcpy(host_data, p->host_stage, bytes, hipMemcpyDeviceToHost));
     return SDSP_HIP_OK;
@@ -780,6 +809,8 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
         return SDSP_HIP_OK;
     if (!data || !h)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "null pointer");
+    if (p->real_mode) // a real-input plan's transform is not the complex DFT the product is defined on
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "convolve needs a complex plan (real-input plans are not supported)");
     if (int rc = use_device(p->device))
         return rc;
     if (p->path == PATH_FFT4096 && p->variant == 0)
@@ -803,15 +834,13 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
                                               p->max_batch, p->device))
             return rc;
     }
-    const int keep = p->variant;
-    if (p->path == PATH_FFT4096) // variant != 0 selects the three-launch path for cross-checking
-        p->variant = 0;
-    int rc = fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream));
-    p->variant = keep;
+    // PATH_FFT4096 with variant != 0 selects this three-launch path for cross-checking: its transforms run variant 0
+    const int v = p->path == PATH_FFT4096 ? 0 : p->variant;
+    int rc = fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream), v);
     if (!rc)
         rc = launch_pointwise_mul(p->precision, data, h, p->n, batch, stream);
     if (!rc)
-        rc = fft_exec_device(p->partner, data, batch, reinterpret_cast<hipStream_t>(stream));
+        rc = fft_exec_device(p->partner, data, batch, reinterpret_cast<hipStream_t>(stream), p->partner->variant);
     return rc;
 }
 
@@ -885,8 +914,8 @@ int sdsp_hip_iir_plan_create(sdsp_hip_iir_plan **out, uint32_t sections, int kin
     *out = nullptr;
     if (sections == 0 || sections % 2 != 0) // static_assert casc_2o_iir.h:25
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "M must be even!");
-    if (sections > 8)
-        return fail(SDSP_HIP_ERR_UNSUPPORTED, "at most 8 sections are compiled in");
+    if (sections > SDSP_HIP_MAX_SECTIONS) // 2 .. 8: the tuned kernels; 10 .. 16: the direct kernel
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "at most SDSP_HIP_MAX_SECTIONS (16) sections are compiled in");
     if (kind < SDSP_HIP_IIR_GENERIC || kind > SDSP_HIP_IIR_BP)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
     if (!a || (kind == SDSP_HIP_IIR_GENERIC && !b))

@@ -227,14 +227,11 @@ int launch_fft1m_pass(const fft1m_args &a, int which, void *stream)
     const float2 *twn = reinterpret_cast<const float2 *>(a.tw_n);
     const float2 *tw1k = reinterpret_cast<const float2 *>(a.tw_1024);
     constexpr size_t kColsLds = 1024 * kTile * sizeof(float) + 1024 * sizeof(float2) + 32 * kTile * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sdsp_fft1m_cols<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sdsp_fft1m_cols<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done_rev{ 0 }, attr_done_fwd{ 0 };
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft1m_cols<true>), kColsLds, attr_done_rev))
+        return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft1m_cols<false>), kColsLds, attr_done_fwd))
+        return rc;
     const dim3 grid((uint32_t)blocks), block(kThreads);
     if (which == 1) {
         if (a.reverse)

@@ -148,11 +148,9 @@ template <int L, bool REV, bool NT, int G = 1> int launch_l(const fft_reg_args &
     constexpr size_t lds = (sizeof(float) << L) * G;
     auto kern = sdsp_fft_big_kernel<L, REV, NT, G>;
     if constexpr (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> attr_done{ 0 };
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
+            return rc;
     }
     const uint64_t blocks = (a.batch + G - 1) / G;
     if (blocks > 0x7fffffffull)

@@ -276,20 +276,19 @@ __global__ __launch_bounds__(points_for(LOG2N) / 16) void sdsp_fft_reg_kernel(fl
 }
 
 template <int RADIX, int LOG2N, bool REV, bool NT, int MODE>
-void launch_one(const fft_reg_args &a, dim3 grid, hipStream_t s)
+int launch_one(const fft_reg_args &a, dim3 grid, hipStream_t s)
 {
     constexpr int kPoints = points_for(LOG2N);
     constexpr size_t lds = (size_t)(kPoints + kPoints / 16) * sizeof(float2);
     auto kern = sdsp_fft_reg_kernel<RADIX, LOG2N, REV, NT, MODE>;
     if constexpr (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> attr_done{ 0 };
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
+            return rc;
     }
     hipLaunchKernelGGL(kern, grid, dim3(kPoints / 16), lds, s, reinterpret_cast<float2 *>(a.data),
                        reinterpret_cast<const float2 *>(a.tw), reinterpret_cast<const float2 *>(a.tw2), a.batch, a.scale);
+    return SDSP_HIP_OK;
 }
 
 template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t s)
@@ -299,23 +298,20 @@ template <int RADIX, int LOG2N> int launch_n(const fft_reg_args &a, hipStream_t 
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     const dim3 grid((uint32_t)blocks);
+    int rc;
     if (a.real_mode == 1) { // real forward: always the forward direction, streaming accesses
-        launch_one<RADIX, LOG2N, false, true, 1>(a, grid, s);
+        rc = launch_one<RADIX, LOG2N, false, true, 1>(a, grid, s);
     } else if (a.real_mode == 2) { // real inverse
-        launch_one<RADIX, LOG2N, true, true, 2>(a, grid, s);
+        rc = launch_one<RADIX, LOG2N, true, true, 2>(a, grid, s);
     } else if (a.real_mode == 3) { // fused convolution: forward plan, tw2 = h
-        launch_one<RADIX, LOG2N, false, true, 3>(a, grid, s);
+        rc = launch_one<RADIX, LOG2N, false, true, 3>(a, grid, s);
     } else if (a.nontemporal) {
-        if (a.reverse)
-            launch_one<RADIX, LOG2N, true, true, 0>(a, grid, s);
-        else
-            launch_one<RADIX, LOG2N, false, true, 0>(a, grid, s);
+        rc = a.reverse ? launch_one<RADIX, LOG2N, true, true, 0>(a, grid, s) : launch_one<RADIX, LOG2N, false, true, 0>(a, grid, s);
     } else {
-        if (a.reverse)
-            launch_one<RADIX, LOG2N, true, false, 0>(a, grid, s);
-        else
-            launch_one<RADIX, LOG2N, false, false, 0>(a, grid, s);
+        rc = a.reverse ? launch_one<RADIX, LOG2N, true, false, 0>(a, grid, s) : launch_one<RADIX, LOG2N, false, false, 0>(a, grid, s);
     }
+    if (rc)
+        return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_reg launch: ") + hipGetErrorString(e));

@@ -565,6 +565,18 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
     return SDSP_HIP_OK;
 }
 
+// m_t = 10 .. 16 (the reference accepts any even M, casc_2o_iir.h:25): correct through the direct kernel, not tuned
+template <typename R, int KIND, int M> int launch_direct(const iir_args &a, hipStream_t stream)
+{
+    const auto p = make_args<R, M>(a);
+    const uint64_t blocks = (a.channels + 255) / 256;
+    hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
 template <typename R, int KIND> int launch_k(const iir_args &a, int variant, hipStream_t stream)
 {
     switch (a.sections) {
@@ -572,7 +584,11 @@ template <typename R, int KIND> int launch_k(const iir_args &a, int variant, hip
     case 4: return launch_km<R, KIND, 4>(a, variant, stream);
     case 6: return launch_km<R, KIND, 6>(a, variant, stream);
     case 8: return launch_km<R, KIND, 8>(a, variant, stream);
-    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be 2, 4, 6 or 8");
+    case 10: return launch_direct<R, KIND, 10>(a, stream);
+    case 12: return launch_direct<R, KIND, 12>(a, stream);
+    case 14: return launch_direct<R, KIND, 14>(a, stream);
+    case 16: return launch_direct<R, KIND, 16>(a, stream);
+    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be even and at most 16");
     }
 }
 
@@ -635,7 +651,12 @@ template <typename R, int KIND> int launch_il_k(const iir_args &a, int variant, 
     case 4: return launch_il_km<R, KIND, 4>(a, variant, stream);
     case 6: return launch_il_km<R, KIND, 6>(a, variant, stream);
     case 8: return launch_il_km<R, KIND, 8>(a, variant, stream);
-    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be 2, 4, 6 or 8");
+    // m_t = 10 .. 16: one channel per lane, four rows in flight (correct, not tuned)
+    case 10: return launch_il_v<R, KIND, 10, 1, 4>(a, true, stream);
+    case 12: return launch_il_v<R, KIND, 12, 1, 4>(a, true, stream);
+    case 14: return launch_il_v<R, KIND, 14, 1, 4>(a, true, stream);
+    case 16: return launch_il_v<R, KIND, 16, 1, 4>(a, true, stream);
+    default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be even and at most 16");
     }
 }
 template <typename R> int launch_il_r(const iir_args &a, int variant, hipStream_t stream)

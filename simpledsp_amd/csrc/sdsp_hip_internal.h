@@ -3,6 +3,7 @@
 
 #include "sdsp_hip.h"
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -11,6 +12,11 @@ namespace sdsp_hip
 {
 extern thread_local std::string g_last_error;
 int fail(int code, const std::string &msg);
+
+// Raise a kernel's dynamic-LDS limit (needed above 64 KiB).  The attribute belongs to the function object of the
+// CURRENT device, so it is set once per (kernel, device): `done` is the caller's per-kernel mask, bit = device index.
+// Safe from concurrent host threads (sharded entry points run one thread per device).  Defined in capi.hip.
+int ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
 
 // host_math.cpp
 void make_twiddles(uint32_t n, int direction, std::vector<double> &out);

@@ -142,6 +142,8 @@ class FftPlan:
             raise ValueError("convolve needs device tensors of the plan's complex dtype")
         if not x.is_contiguous() or not h.is_contiguous() or x.shape[-1] != self.n or h.numel() != self.n:
             raise ValueError("convolve needs contiguous x (..., n) and h (n,)")
+        if x.device.index != self.device or h.device.index != self.device:
+            raise ValueError("tensors live on a different device than the plan")
         stream = torch.cuda.current_stream(x.device).cuda_stream
         L.check(self._lib.sdsp_hip_fft_convolve(self._h, x.data_ptr(), h.data_ptr(), x.numel() // self.n, stream))
         return x
@@ -180,6 +182,8 @@ class RfftPlan:
         import torch
         if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.n_real:
             raise ValueError("exec needs a contiguous float32 device tensor (..., n_real)")
+        if x.device.index != self.device:
+            raise ValueError("tensor lives on a different device than the plan")
         stream = torch.cuda.current_stream(x.device).cuda_stream
         L.check(self._lib.sdsp_hip_fft_exec(self._h, x.data_ptr(), x.numel() // self.n_real, stream))
         if self.direction == L.FORWARD:

@@ -95,13 +95,15 @@ class fir_filter:
             raise ValueError("process needs a contiguous (channels, samples) device tensor of the bank dtype")
         if data.shape[0] != self.channels:
             raise ValueError("channel count differs from the bank's")
+        if data.device.index != self.device:
+            raise ValueError("tensor lives on a different device than the bank")
         stride = data.shape[1]
         samples = stride - offset if samples is None else samples
         if offset + samples > stride:
             raise ValueError("block exceeds the row")
         self._ensure_plan()
         if self._state is None:
-            self._state = torch.zeros((self.channels, max(self.n_taps - 1, 1)), dtype=dt, device=data.device)
+            self._state = torch.zeros((self.channels, max(self.n_taps - 1, 1)), dtype=dt, device=f"cuda:{self.device}")
         stream = torch.cuda.current_stream(data.device).cuda_stream
         L.check(self._lib.sdsp_hip_fir_process(self._plan, data.data_ptr() + offset * data.element_size(), self.channels,
                                                samples, stride, self._state.data_ptr(), stream))

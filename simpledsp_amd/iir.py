@@ -118,13 +118,15 @@ class casc_2o_iir:
             raise ValueError("process needs a contiguous (channels, samples) device tensor of the bank dtype")
         if data.shape[0] != self.channels:
             raise ValueError("channel count differs from the bank's")
+        if data.device.index != self.device:
+            raise ValueError("tensor lives on a different device than the bank")
         stride = data.shape[1]
         samples = stride - offset if samples is None else samples
         if offset + samples > stride:
             raise ValueError("block exceeds the row")
         self._ensure_plan()
         if self._state is None:
-            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=data.device)
+            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=f"cuda:{self.device}")
         stream = torch.cuda.current_stream(data.device).cuda_stream
         L.check(self._lib.sdsp_hip_iir_process(self._plan, data.data_ptr() + offset * data.element_size(),
                                                self.channels, samples, stride, self._state.data_ptr(), stream))
@@ -140,12 +142,14 @@ class casc_2o_iir:
             raise ValueError("process_interleaved needs a contiguous (samples, channels) device tensor")
         if data.shape[1] != self.channels:
             raise ValueError("channel count differs from the bank's")
+        if data.device.index != self.device:
+            raise ValueError("tensor lives on a different device than the bank")
         samples = data.shape[0] - offset if samples is None else samples
         if offset + samples > data.shape[0]:
             raise ValueError("block exceeds the buffer")
         self._ensure_plan()
         if self._state is None:
-            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=data.device)
+            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=f"cuda:{self.device}")
         stream = torch.cuda.current_stream(data.device).cuda_stream
         L.check(self._lib.sdsp_hip_iir_process_interleaved(
             self._plan, data.data_ptr() + offset * self.channels * data.element_size(), self.channels, samples,

@@ -6,11 +6,14 @@
 // tolerances, plus checks of the batched entries.  Usage: test_dropin <dir with the 9 impulse CSVs>
 // Exit code 0 = all passed, 1 = assertion failures, 3 = the GPU path is unavailable (no fallback).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <deque>
 #include <filesystem>
 #include <fstream>
 #include <limits>
+#include <list>
 #include <random>
 #include <string>
 #include <tuple>
@@ -591,6 +594,111 @@ void test_next_rows()
     REQUIRE(same);
 }
 
+// Round 2 boundary checks: the reference's process(iter_t, iter_t) (casc_2o_iir.h:36-37) takes ANY iterator pair,
+// filter objects are values (copy = coefficients and state, testIIR.cpp:48), and a caller streaming short blocks
+// (testIIR.cpp:61-75) must not pay a plan build per call.
+void test_iterators_copies_and_streaming_cost()
+{
+    std::mt19937_64 rng(7);
+    std::normal_distribution<double> nd;
+    std::vector<double> x(1000);
+    for (auto &v : x)
+        v = nd(rng);
+
+    sdsp::casc_2o_iir<4> f;
+    f.set_bp_coeff(2000.0, 39e3, 0.8);
+    auto whole = x;
+    {
+        auto g = f;
+        g.process(whole.begin(), whole.end());
+    }
+    // non-contiguous containers: same doubles as the vector run
+    {
+        std::deque<double> dq(x.begin(), x.end());
+        auto g = f;
+        g.process(dq.begin(), dq.end());
+        REQUIRE(std::equal(dq.begin(), dq.end(), whole.begin()));
+        std::list<double> ls(x.begin(), x.end());
+        auto h = f;
+        h.process(ls.begin(), ls.end());
+        REQUIRE(std::equal(ls.begin(), ls.end(), whole.begin()));
+    }
+    // a copy taken mid-stream continues exactly like the original (state is part of the value; the device-side
+    // cache is not), and re-designing one of them does not disturb the other
+    {
+        auto a = f;
+        auto y = x;
+        a.process(y.begin(), y.begin() + 400);
+        auto b = a;
+        a.process(y.begin() + 400, y.end());
+        REQUIRE(y == whole);
+        auto y2 = x;
+        std::copy(y.begin(), y.begin() + 400, y2.begin());
+        b.process(y2.begin() + 400, y2.end());
+        REQUIRE(y2 == whole);
+        b.set_lp_coeff(5000.0, 39e3);
+        auto y3 = x, y4 = x;
+        a = f;
+        a.process(y3.begin(), y3.end());
+        REQUIRE(y3 == whole);
+        sdsp::casc_2o_iir<4> lp;
+        lp.set_lp_coeff(5000.0, 39e3);
+        sdsp::casc_2o_iir<4> b2;
+        b2.copy_coeff_from(b);
+        b2.process(y4.begin(), y4.end());
+        auto y5 = x;
+        lp.process(y5.begin(), y5.end());
+        REQUIRE(y4 == y5);
+    }
+    // streaming 32-sample blocks (testIIR.cpp:61-75): bit-identical, and the per-call cost is a few transfers, not a
+    // plan build plus two hipMalloc/hipFree pairs (the first call pays the one-off setup and is left out)
+    {
+        auto g = f;
+        std::vector<double> stream(32 * 201);
+        for (auto &v : stream)
+            v = nd(rng);
+        auto ref = stream;
+        {
+            auto r = f;
+            r.process(ref.begin(), ref.end());
+        }
+        g.process(stream.begin(), stream.begin() + 32);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t blk = 1; blk < 201; ++blk)
+            g.process(stream.begin() + static_cast<std::ptrdiff_t>(32 * blk), stream.begin() + static_cast<std::ptrdiff_t>(32 * (blk + 1)));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 200.0;
+        REQUIRE(stream == ref);
+        std::printf("streaming 32-sample blocks through sdsp::casc_2o_iir<4>::process: %.1f us per call\n", us);
+        REQUIRE(us < 2000.0);
+    }
+    // more than 8 sections (the reference accepts any even M): served by the direct kernel
+    {
+        sdsp::casc_2o_iir<10> big;
+        big.set_lp_coeff(10e3, 100e3);
+        std::vector<double> imp(256, 0.0);
+        imp[0] = 1.0;
+        big.process(imp.begin(), imp.end());
+        double sum = 0;
+        for (double v : imp)
+            sum += v;
+        REQUIRE(std::abs(sum - 1.0) < 1e-6); // unit DC gain: the impulse response sums to 1
+    }
+    // calc_trigs_naive (fft.h:54-65) beside calc_trigs
+    {
+        const auto n = sdsp::calc_trigs_naive<64, sdsp::cosine_calculator>();
+        const auto c = sdsp::calc_trigs<64, sdsp::cosine_calculator>();
+        REQUIRE(n.size() == 6 && n[5][0] == 1.0 && n[0][1] == std::cos(2 * M_PI * 1 / 2.0));
+        double worst = 0;
+        for (size_t i = 0; i < n.size(); ++i)
+            for (size_t j = 0; j < 64; ++j)
+                worst = std::max(worst, std::abs(n[i][j] - c[i][j]));
+        REQUIRE(worst < 1e-13); // the naive table evaluates large angles directly (error ~ angle * eps, 9e-15 here) and
+                                // lacks the exact symmetry (cos(pi/2) = 6e-17); nothing more
+        const auto sn = sdsp::calc_trigs_naive<16, sdsp::sine_calculator>();
+        REQUIRE(sn[3][4] == std::sin(2 * M_PI * 4 / 16.0));
+    }
+}
+
 int main(int argc, char **argv)
 {
     const std::string csv_dir = argc > 1 ? argv[1] : "tests/golden/impulse_response";
@@ -609,6 +717,7 @@ int main(int argc, char **argv)
         test_next_rows();
         test_band_stop();
         test_fir();
+        test_iterators_copies_and_streaming_cost();
     } catch (const sdsp::hip_error &e) {
         std::printf("GPU path unavailable (no CPU fallback): %s (code %d)\n", e.what(), e.code());
         return 3;

@@ -463,10 +463,10 @@ def test_sharded_entry_with_several_plans(sd, torch_cuda, oracle):
     assert sd.load().sdsp_hip_fft_exec_sharded(arr2, 2, y.ctypes.data, 11) == L.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("batch", [65536])
+@pytest.mark.parametrize("batch", [65536, 262144])
 def test_baseline_config2_full_size_properties(sd, torch_cuda, oracle, batch):
-    """BASELINE config 2 at full size (65536 x 4096 f32, 2 GiB): size-independent properties +
-    spot checks against the oracle."""
+    """BASELINE config 2 at full size (65536 x 4096 f32, 2 GiB) and one config-5 shard (2M transforms / 8 GPUs =
+    262144 x 4096 f32, 8 GiB, on this one GPU): size-independent properties + spot checks against the oracle."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(0x5D5B)
     x = torch.randn((batch, 4096, 2), generator=g, device="cuda", dtype=torch.float32)
@@ -488,3 +488,34 @@ def test_baseline_config2_full_size_properties(sd, torch_cuda, oracle, batch):
     num = (y - x).abs().amax(dim=1)
     den = x.abs().amax(dim=1)
     assert float((num / den).max()) < TOL32
+
+
+def test_convolve_rejects_real_input_plans(sd, torch_cuda):
+    # a real-input plan's transform is not the complex DFT the product is defined on: UNSUPPORTED, not a wrong answer
+    from simpledsp_amd import _lib as L
+    plan = sd.RfftPlan(1024, 2, sd.forward_fft, max_batch=2)
+    x = torch_cuda.zeros((2, 512), dtype=torch_cuda.complex64, device="cuda")
+    h = torch_cuda.ones((512,), dtype=torch_cuda.complex64, device="cuda")
+    rc = sd.load().sdsp_hip_fft_convolve(plan._h, x.data_ptr(), h.data_ptr(), 2, None)
+    assert rc == L.ERR_UNSUPPORTED
+
+
+def test_plans_on_a_second_device(sd, torch_cuda, oracle):
+    """Kernels that need more than 64 KiB of dynamic LDS raise that limit per DEVICE (the attribute belongs to the
+    function object of the current device): plans on device 1 must launch too.  Needs two GPUs; the driver's
+    one-GPU box skips it."""
+    torch = torch_cuda
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    rng = np.random.default_rng(77)
+    for n, radix in ((8192, 2), (16384, 4), (1 << 20, 2)):
+        x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+        want = np.fft.fft(x.astype(np.complex128), axis=-1)
+        for dev in (0, 1):
+            plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=2, device=dev)
+            d = torch.from_numpy(x).to(f"cuda:{dev}")
+            plan.exec(d)
+            torch.cuda.synchronize(dev)
+            assert rel_max_err(d.cpu().numpy(), want) < TOL32, (n, dev)
+        with pytest.raises(ValueError):
+            plan.exec(torch.from_numpy(x).to("cuda:0"))  # plan on device 1, tensor on device 0

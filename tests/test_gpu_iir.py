@@ -118,6 +118,33 @@ def test_section_counts_and_kinds_f64_bit_exact(sd, torch_cuda, iir_golden, m):
             assert np.array_equal(out[69], out[0])
 
 
+@pytest.mark.parametrize("m", [10, 12, 16])
+def test_more_than_eight_sections(sd, torch_cuda, oracle, m):
+    """The reference accepts any even M (casc_2o_iir.h:25); 10 .. 16 sections run the direct kernel (correct, not
+    tuned).  f64 bit-exact against the oracle's recurrence, every kind, both layouts; 18 is refused."""
+    rng = np.random.default_rng(m)
+    x = rng.standard_normal((70, 300))
+    for nm, ftype in KINDS.items():
+        for kind in (sd.IIR_GENERIC, ftype):
+            fo = oracle.iir(m)
+            design(fo, ftype, 3e3, 48e3, 0.9)
+            want = fo.process(x[5], kind)
+            bank = _bank(sd, m, 70, sd.F64, kind, ftype, 3e3, 48e3, 0.9)
+            out = _process(torch_cuda, bank, x)
+            assert np.array_equal(out[5], want), (m, nm, kind)
+            bank_il = _bank(sd, m, 70, sd.F64, kind, ftype, 3e3, 48e3, 0.9)
+            d = torch_cuda.from_numpy(np.ascontiguousarray(x.T)).cuda()
+            bank_il.process_interleaved(d)
+            torch_cuda.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy().T, out)
+    b32 = _bank(sd, m, 70, sd.F32, sd.IIR_GENERIC, 1, 10e3, 100e3, 0.0)
+    fo = oracle.iir(m)
+    fo.set_lp_coeff(10e3, 100e3)
+    assert rel_max_err(_process(torch_cuda, b32, x.astype(np.float32))[7], fo.process(x[7].astype(np.float32).astype(np.float64))) < 3e-6
+    with pytest.raises(sd.SdspHipError):
+        _process(torch_cuda, _bank(sd, 18, 2, sd.F64, sd.IIR_GENERIC, 1, 3e3, 48e3, 0.0), x[:2])
+
+
 @pytest.mark.parametrize("channels,samples", [(1, 4096), (63, 128), (65, 96), (300, 4096), (1024, 1000), (257, 36)])
 def test_f32_bank_against_oracle(sd, torch_cuda, oracle, channels, samples):
     # BASELINE config-4 filter: casc_2o_iir<4> LP, fs=100k, f0=10k (testIIR.cpp:469-474)
