@@ -59,7 +59,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    headers = [CSRC / "sdsp_hip_internal.h", CSRC / "fft_passes.h", CSRC / "fft32.h", ROOT / "include" / "sdsp_hip.h", Path(__file__)]
+    headers = [CSRC / "sdsp_hip_internal.h", CSRC / "fft_passes.h", CSRC / "fft32.h", CSRC / "fft1m_kernels.h", CSRC / "fft4096_kernels.h", ROOT / "include" / "sdsp_hip.h", Path(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -9,12 +9,6 @@
 
 #include "sdsp_hip_internal.h"
 
-// one pass of the tuned 2^20 path (defined in fft1m.hip): which = 1 columns pass, 2 rows pass
-namespace sdsp_hip
-{
-int launch_fft1m_pass(const fft1m_args &a, int which, void *stream);
-}
-
 using namespace sdsp_hip;
 
 int sdsp_hip::ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done)
@@ -158,6 +152,8 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
     return SDSP_HIP_OK;
 }
 
+constexpr uint64_t kFft1mRing = 8;        // intermediate ring of the N = 2^20 persistent kernel (transforms)
+constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
@@ -182,9 +178,8 @@ struct sdsp_hip_fft_plan {
     uint64_t twiddle_bytes = 0;
     void *host_stage = nullptr;    // device staging buffer of the *_host path
     uint64_t host_stage_bytes = 0;
-    // two-stream pipelining of the N=2^20 passes (created on first use)
-    hipStream_t aux_stream = nullptr;
-    std::vector<hipEvent_t> events;
+    void *sync = nullptr;          // N = 2^20: the persistent kernel's ticket / arrival counters
+    uint64_t sync_count = 0;       // ... transforms one launch of it covers
     sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
     sdsp_hip_fft_plan *mid_rows = nullptr; // N = 2^16 .. 2^19 f32: plan of the 16 row transforms (fft_mid.hip)
     void *tw1024 = nullptr;                // ... and W_1024^j, the coarse factor of its inter-pass twiddle
@@ -248,15 +243,13 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r4_f32(a, variant, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (variant == 0 || variant == 3) && p->n == 4096 &&
-        p->radix == 2 && !p->real_mode) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->n == 4096 && p->radix == 2 && !p->real_mode) {
         fft4096_args a;
         a.data = data;
         a.tw = p->twt;
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
-        a.pair = variant == 3; // 3: two consecutive transforms per workgroup
         return launch_fft4096_r2_f32(a, stream);
     }
 
@@ -335,34 +328,22 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (int rc = ensure_workspace(p)) // every path below is multi-pass
         return rc;
 
-    if (p->path == PATH_FFT1M && variant < 8) {
-        // Chunked so that a chunk's intermediate matrices are still in the 256 MiB Infinity Cache when
-        // pass 2 reads them.  variant -> (chunk, overlap).  With overlap the workspace is used as two
-        // halves and pass 1 of chunk i+1 (HBM reads) runs on the caller's stream while pass 2 of
-        // chunk i (HBM writes) runs on an internal stream; events order the hand-offs.
-        static const uint64_t chunk_of[8] = { 32, 16, 16, 8, 24, 12, 8, 4 };
-        static const bool overlap_of[8] = { false, true, false, true, false, true, false, true };
-        // the two-stream variants need two workspace halves: a plan created for a single transform has one, and
-        // runs them serially (found by the randomised cross-check: half 1 used to start past the end of a
-        // one-transform workspace)
-        const bool overlap = overlap_of[variant] && p->ws_batch >= 2;
-        const uint64_t cap = overlap ? p->ws_batch / 2 : p->ws_batch;
-        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk_of[variant], cap));
+    if (p->path == PATH_FFT1M && variant < 3) {
         const uint64_t N = 1ull << 20;
-        auto args_for = [&](uint64_t done, int half) {
-            fft1m_args a;
-            a.data = reinterpret_cast<char *>(data) + done * N * 8;
-            a.workspace = reinterpret_cast<char *>(p->workspace) + (half ? chunk * N * 8 : 0);
-            a.tw_n = p->tw;
-            a.tw_1024 = p->tw1;
-            a.count = std::min<uint64_t>(chunk, batch - done);
-            a.scale = (float)(1.0 / (double)N);
-            a.reverse = rev;
-            return a;
-        };
-        if (!overlap) {
+        const float scale = (float)(1.0 / (double)N);
+        if (variant == 1) {
+            // round 1's schedule: two launches per chunk of <= 32 transforms, the chunk's intermediate matrices still
+            // (partly) in the 256 MiB Infinity Cache when pass 2 reads them
+            const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch));
             for (uint64_t done = 0; done < batch; done += chunk) {
-                const fft1m_args a = args_for(done, 0);
+                fft1m_args a;
+                a.data = reinterpret_cast<char *>(data) + done * N * 8;
+                a.workspace = p->workspace;
+                a.tw_n = p->tw;
+                a.tw_1024 = p->tw1;
+                a.count = std::min<uint64_t>(chunk, batch - done);
+                a.scale = scale;
+                a.reverse = rev;
                 if (int rc = launch_fft1m_pass(a, 1, stream))
                     return rc;
                 if (int rc = launch_fft1m_pass(a, 2, stream))
@@ -370,30 +351,25 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             }
             return SDSP_HIP_OK;
         }
-        if (!p->aux_stream)
-            HIP_TRY(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
-        const uint64_t n_chunks = (batch + chunk - 1) / chunk;
-        while (p->events.size() < 2 * n_chunks) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            p->events.push_back(e);
-        }
-        for (uint64_t i = 0; i < n_chunks; i++) {
-            const fft1m_args a = args_for(i * chunk, (int)(i & 1));
-            hipEvent_t cols_done = p->events[2 * i], rows_done = p->events[2 * i + 1];
-            if (i >= 2) // this workspace half was last read by pass 2 of chunk i-2
-                HIP_TRY(hipStreamWaitEvent(stream, p->events[2 * (i - 2) + 1], 0));
-            if (int rc = launch_fft1m_pass(a, 1, stream))
+        // default: ONE persistent launch; pass 2 of transform t runs `lag` ticket steps behind pass 1, the
+        // intermediate lives in a ring of `ring` transforms (fft1m_kernels.h).  variant 2: row-major intermediate.
+        const uint32_t ring = (uint32_t)std::min<uint64_t>(p->ws_batch, kFft1mRing);
+        const uint32_t lag = ring > 2 ? ring - 2 : ring - 1;
+        for (uint64_t done = 0; done < batch; done += p->sync_count) {
+            fft1m_fused_args a;
+            a.data = reinterpret_cast<char *>(data) + done * N * 8;
+            a.workspace = p->workspace;
+            a.tw_1024 = p->tw1;
+            a.sync = p->sync;
+            a.count = std::min<uint64_t>(p->sync_count, batch - done);
+            a.ring = ring;
+            a.lag = lag;
+            a.layout = variant == 2 ? 0 : 1;
+            a.scale = scale;
+            a.reverse = rev;
+            if (int rc = launch_fft1m_fused(a, stream))
                 return rc;
-            HIP_TRY(hipEventRecord(cols_done, stream));
-            HIP_TRY(hipStreamWaitEvent(p->aux_stream, cols_done, 0));
-            if (int rc = launch_fft1m_pass(a, 2, p->aux_stream))
-                return rc;
-            HIP_TRY(hipEventRecord(rows_done, p->aux_stream));
         }
-        // the caller's stream is complete only when every pass 2 is
-        for (uint64_t i = (n_chunks >= 2 ? n_chunks - 2 : 0); i < n_chunks; i++)
-            HIP_TRY(hipStreamWaitEvent(stream, p->events[2 * i + 1], 0));
         return SDSP_HIP_OK;
     }
 
@@ -635,9 +611,15 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->twiddle_bytes = ((uint64_t)n + p->n1 + p->n2) * esize(precision);
         pick_tile(precision, p->n1, 16, &p->cols1, &p->pitch1);
         pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
-        // the tuned 2^20 path runs chunk by chunk and never needs more than 32 intermediate matrices
+        // the tuned 2^20 path keeps a ring of intermediates (8 for the persistent kernel, 32 for variant 1's chunks)
         p->ws_batch = p->path == PATH_FFT1M ? std::min<uint64_t>(p->max_batch, 32) : p->max_batch;
         p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
+        if (!rc && p->path == PATH_FFT1M) {
+            p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
+            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count));
+            if (e != hipSuccess)
+                rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft1m counters hipMalloc: ") + hipGetErrorString(e));
+        }
     }
     // three-pass schedule (fft_mid.hip): f32 N = 2^16 .. 2^23 (2^20 is PATH_FFT1M); f64 N = 2^14 .. 2^21 -- the rows
     // then land on the f64 register-pass family (N <= 8192) or, nested, on another three-pass plan
@@ -712,10 +694,7 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
             sdsp_hip_fft_plan_destroy(p->mid_rows);
         p->mid_rows = nullptr;
         (void)hipSetDevice(p->device);
-        for (hipEvent_t e : p->events)
-            (void)hipEventDestroy(e);
-        if (p->aux_stream)
-            (void)hipStreamDestroy(p->aux_stream);
+        (void)hipFree(p->sync);
     }
     delete p;
     return SDSP_HIP_OK;
@@ -868,14 +847,12 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->twiddle_bytes = p->twiddle_bytes;
     const char *name = "sdsp_fft_tile_kernel";
     if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants())
-        name = fft4096_kernel_name(p->variant);
-    if (p->path == PATH_FFT1M && p->variant < 8)
-        name = "sdsp_fft1m_cols+sdsp_fft1m_rows";
+        name = "sdsp_fft4096_r4_f32";
+    if (p->path == PATH_FFT1M && p->variant < 3)
+        name = p->variant == 1 ? "sdsp_fft1m_cols+sdsp_fft1m_rows" : "sdsp_fft1m_fused";
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->n == 4096 && p->radix == 2 && p->variant == 3 && !p->real_mode)
-        name = "sdsp_fft4096_r2_f32"; // its two-transforms-per-workgroup variant
     if (big)
         name = "sdsp_fft_big_kernel";
     if (mid)

@@ -1,0 +1,398 @@
+// fft1m_kernels.h -- device code of the batched N = 2^20 radix-2 complex f32 FFT (BASELINE config 3) for gfx950.
+// Included by fft1m.hip (the product) and by tools/lab_fft1m.hip (the measurement harness, which also builds the
+// MATH = false data movers with the same access patterns).
+//
+// sdsp::fft_radix2<T, 2^20> (fft.h:258-299) cannot even be compiled in the reference (its table would be 320 MiB
+// of constexpr data); here the 20 radix-2 butterfly stages run as a four-step decomposition N = 1024 x 1024 with
+// the transform viewed as a row-major [n1][n2] matrix:
+//
+//   pass 1 (cols_tile)  for 16 adjacent columns n2: ten radix-2 stages over n1 (stride 1024), times the inter-pass
+//                       twiddle W_N^(n2*k1), written to the intermediate
+//   pass 2 (rows_tile)  for 16 adjacent rows k1: ten radix-2 stages over n2, written transposed,
+//                       X[k1 + 1024*k2], back into the caller's buffer
+//
+// Both passes use the same building block: 512 threads = 16 sequences x 32 threads, 32 points per thread in
+// registers, two register passes of five radix-2 DIF stages each (fft32.h), ONE exchange through LDS.  The exchange
+// moves the real and the imaginary plane separately, so a 1024 x 16 tile costs 64 KiB instead of 128 KiB and two
+// workgroups fit a CU.  Stage twiddles: five per-thread values W_1024^(2^s u) (from an LDS copy of W_1024) times
+// compile-time W_32 constants.  LDS planes are XOR-swizzled so all ds_read/ds_write_b32 are bank-conflict free.
+//
+// Two schedules over these tiles:
+//   * sdsp_fft1m_fused: ONE persistent launch per batch.  Workgroups draw tickets from a global counter; the ticket
+//     order interleaves pass-1 tiles of transform t + D with pass-2 tiles of transform t, so the two passes share the
+//     CUs all the time, the intermediate of a transform is consumed a few microseconds after it was produced (a ring
+//     of R << 32 transforms that stays in the 256 MiB Infinity Cache) and HBM sees the compulsory read and write
+//     once each.  Hand-off between workgroups: agent-scope release / acquire on per-transform arrival counters.
+//   * sdsp_fft1m_cols + sdsp_fft1m_rows: two launches per chunk of 32 transforms (round 1's schedule; kept as the
+//     plan's variant 1 for A/B measurements).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fft32.h"
+
+namespace sdsp_hip
+{
+namespace fft1m
+{
+using namespace fft32;
+
+constexpr int kTile = 16;      // sequences per tile
+constexpr int kThreads = 512;  // 16 sequences x 32 threads
+constexpr int kTiles = 1024 / kTile;
+// dynamic LDS: one real plane [row][col] (64 KiB), W_1024 (8 KiB), the column part of the inter-pass twiddle (4 KiB),
+// the fused kernel's ticket mailbox (16 B)
+constexpr size_t kPlaneBytes = 1024 * kTile * sizeof(float);
+constexpr size_t kLdsBytes = kPlaneBytes + 1024 * sizeof(float2) + 32 * kTile * sizeof(float2) + 16;
+
+// Intermediate layouts.  ROWS: the [k1][n2] matrix itself (pass 1 writes 128-B segments 8 KiB apart, pass 2 reads
+// whole 8 KiB rows).  BLOCKED: [n2 / 16][k1][n2 % 16] -- a pass-1 tile's output is ONE contiguous 128 KiB block,
+// pass 2 gathers 2 KiB pieces (16 rows x 128 B) from each of the 64 blocks.
+enum ws_layout { WS_ROWS = 0, WS_BLOCKED = 1 };
+// What a tile does.  MODE_FFT is the product.  The other two exist for tools/lab_fft1m.hip only: the same loads and
+// stores without the butterflies (MODE_MOVE), and without the intermediate's traffic either (MODE_HBM_ONLY: what the
+// HBM-facing halves of the two passes cost on their own).
+enum tile_mode { MODE_MOVE = 0, MODE_FFT = 1, MODE_HBM_ONLY = 2 };
+
+// ---- pass 1: 16 columns of one transform ------------------------------------------------------
+// in_x / ws_x: the transform's input matrix / its intermediate.  w1k (LDS): W_1024^j, staged by the caller.
+template <bool REV, int MODE, int LAYOUT, bool NT_IN>
+__device__ __forceinline__ void cols_tile(const float2 *in_x, float2 *ws_x, uint32_t tile, float *plane, const float2 *w1k,
+                                          float2 *qtab)
+{
+    constexpr bool MATH = MODE == MODE_FFT;
+    const uint32_t t = threadIdx.x;
+    const uint32_t c = t & 15, u = t >> 4;
+    const uint32_t n2 = tile * kTile + c;
+    // addresses = wave-uniform base (SGPRs; the per-k part is a compile-time constant) + ONE 32-bit
+    // per-thread offset, so the 32 loads / stores share a single offset register
+    const float2 *src_tile = in_x + tile * kTile;
+    const uint32_t toff = (u * 1024 + c) * 8u; // bytes
+
+    float2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = NT_IN ? nt_load(at(src_tile + 32768 * k, toff)) : *at(src_tile + 32768 * k, toff);
+
+    // W_N^m = W_1024^(m >> 10) * W_N^(m & 1023).  The coarse factor comes from the LDS table; the fine factor
+    // has an angle below 2*pi/1024 = 0.0062 rad, where cos = 1 - t^2/2 and sin = t - t^3/6 are exact to fp32
+    // rounding (next terms < 6e-11): no second gather.
+    auto twiddle = [&](uint32_t m) {
+        const float th = (float)(m & 1023) * 5.9921124526782858e-06f; // 2*pi / 2^20
+        const float th2 = th * th;
+        const float sn = th - th * th2 * 0.16666667f;
+        const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
+        return cmul(w1k[m >> 10], fine);
+    };
+    const uint32_t bu = brev5(u);
+    float2 pw = float2{ 1.0f, 0.0f };
+    if constexpr (MATH) {
+        // The inter-pass twiddle of output k1 = 32 j + bu of column n2 is W_N^(n2 bu) * W_N^(32 n2 j): the first
+        // factor is one value per thread, the second is shared by the 32 threads of a column -- 16 x 32 values per
+        // workgroup, one per thread, parked in LDS (read back after the exchange barriers below).  That replaces a
+        // polynomial and a conflict-prone table gather per ELEMENT by one conflict-free LDS read and one multiply.
+        qtab[u * 16 + c] = twiddle(32u * n2 * u); // thread (c, u) computes j = u
+        fft32_dif<REV, true>(x, w1k, u);          // stages with row strides 512 .. 32; twiddles W_1024^(2^s u)
+
+        // exchange rows {u + 32k} -> {32u + k}.  slot(row, col) = (row*16 + col) ^ (((row >> 5) & 1) << 4).
+        // Written with two base registers + compile-time offsets (per-element XOR'd addresses would
+        // cost 64 VGPRs): writes flip bit 4 for odd k; reads use slot 512u + c + 16*(k ^ (u&1)).
+        float *const w_even = plane + (u * 16 + c);
+        float *const w_odd = plane + ((u * 16 + c) ^ 16);
+        const int flip = (int)(u & 1) * 16;
+        const float *const r_even = plane + (512 * u + c) + flip;
+        const float *const r_odd = plane + (512 * u + c) - flip;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[512 * k] = x[k].x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k].x = ((k & 1) ? r_odd : r_even)[16 * k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[512 * k] = x[k].y;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k].y = ((k & 1) ? r_odd : r_even)[16 * k];
+        fft32_dif<REV, false>(x, w1k, u); // row strides 16 .. 1
+        pw = twiddle(n2 * bu);            // W_N^(n2 bu)
+    }
+
+    // position 32u + k now holds Y[k1], k1 = bit_reverse10(32u + k) = 32 * bit_reverse5(k) + bu; times W_N^(n2*k1),
+    // stored at row k1 of the intermediate (default cache policy: it is re-read within microseconds)
+    const float2 *const qcol = qtab + c;
+    float2 *dst_tile;
+    uint32_t soff;
+    if constexpr (LAYOUT == WS_BLOCKED) {
+        dst_tile = ws_x + (size_t)tile * (1024 * kTile); // [tile][k1][c]
+        soff = (bu * 16 + c) * 8u;
+    } else {
+        dst_tile = ws_x + tile * kTile; // [k1][n2]
+        soff = (bu * 1024 + c) * 8u;
+    }
+    constexpr int kStep = LAYOUT == WS_BLOCKED ? 32 * 16 : 32 * 1024; // float2 elements between k1 and k1 + 32
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0) // keep at most 8 elements' table reads in flight (register budget)
+            __builtin_amdgcn_sched_barrier(0);
+        float2 v = x[k];
+        if constexpr (MATH)
+            v = cmul(v, cmul(pw, qcol[16 * (int)(__brev((uint32_t)k) >> 27)]));
+        if constexpr (MODE == MODE_HBM_ONLY) {
+            if (v.x == 1.2345e-30f) // never true for the lab's data: keeps the loads alive without the stores
+                *at(dst_tile + kStep * (int)(__brev((uint32_t)k) >> 27), soff) = v;
+        } else {
+            *at(dst_tile + kStep * (int)(__brev((uint32_t)k) >> 27), soff) = v;
+        }
+    }
+}
+
+// ---- pass 2: 16 rows of one transform, written transposed ------------------------------------------
+template <bool REV, int MODE, int LAYOUT, bool NT_OUT>
+__device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *w1k,
+                                          float scale)
+{
+    constexpr bool MATH = MODE == MODE_FFT;
+    const uint32_t t = threadIdx.x;
+    // first register pass: 32 lanes run along a row
+    const uint32_t ra = t >> 5, ua = t & 31;
+    float2 x[32];
+    if constexpr (MODE == MODE_HBM_ONLY) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = float2{ (float)t, (float)k };
+    } else if constexpr (LAYOUT == WS_BLOCKED) {
+        // element n2 = ua + 32k of row k1 = 16 tile + ra lives at [(n2 >> 4)][k1][n2 & 15]
+        const float2 *src = ws_x + (size_t)tile * (kTile * kTile);
+        const uint32_t aoff = ((ua >> 4) * (1024 * kTile) + ra * 16 + (ua & 15)) * 8u;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = *at(src + 2 * k * (1024 * kTile), aoff);
+    } else {
+        const float2 *src = ws_x + (size_t)tile * kTile * 1024;
+        const uint32_t aoff = (ra * 1024 + ua) * 8u; // bytes
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = *at(src + 32 * k, aoff);
+    }
+    // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
+    const uint32_t rb = t & 15, ub = t >> 4;
+    if constexpr (MATH) {
+        fft32_dif<REV, true>(x, w1k, ua);
+        // write slot ra*1024 + ((ua + 32k) ^ (ra | ((k&1) << 4))): the XOR touches the low 5 bits only
+        //   -> bases (ua ^ ra) and (ua ^ ra ^ 16) + 32k;
+        // read slot rb*1024 + ((32ub + k) ^ (rb | ((ub&1) << 4))) = rb*1024 + 32ub + (k ^ rb ^ 16(ub&1)):
+        //   the register index is XOR'ed with a run-time value, so those 32 addresses are rebuilt from an
+        //   opaque value with one v_xor each instead of living in registers across the butterflies.
+        float *const w_even = plane + ra * 1024 + (ua ^ ra);
+        float *const w_odd = plane + ra * 1024 + (ua ^ ra ^ 16);
+        const float *const r_base = plane + rb * 1024 + 32 * ub;
+        const uint32_t rx = rb | ((ub & 1) << 4);
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[32 * k] = x[k].x;
+        __syncthreads();
+        {
+            uint32_t q = rx;
+            asm volatile("" : "+v"(q));
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                x[k].x = r_base[k ^ q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            ((k & 1) ? w_odd : w_even)[32 * k] = x[k].y;
+        __syncthreads();
+        {
+            uint32_t q = rx;
+            asm volatile("" : "+v"(q));
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                x[k].y = r_base[k ^ q];
+        }
+        fft32_dif<REV, false>(x, w1k, ua);
+    }
+
+    // position 32ub + k of row k1 holds X[k1 + 1024*k2], k2 = bit_reverse10(32ub + k): 16 lanes write
+    // 128 contiguous bytes.  Streaming (non-temporal) store of the final result.
+    float2 *dst_tile = out_x + tile * kTile;
+    const uint32_t bu = brev5(ub);
+    const uint32_t boff = (bu * 1024 + rb) * 8u; // bytes
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        float2 v = x[k]; // k2 = bit_reverse5(k)*32 + bit_reverse5(ub)
+        if constexpr (REV && MATH) { // reverse_fft::ScaleValues, fft.h:128-132
+            v.x *= scale;
+            v.y *= scale;
+        }
+        float2 *dst = at(dst_tile + 32768 * (int)(__brev((uint32_t)k) >> 27), boff);
+        if constexpr (NT_OUT)
+            nt_store(dst, v);
+        else
+            *dst = v;
+    }
+}
+
+__device__ __forceinline__ void stage_w1k(float2 *w1k, const float2 *tw_1024)
+{
+    reinterpret_cast<float4 *>(w1k)[threadIdx.x] = reinterpret_cast<const float4 *>(tw_1024)[threadIdx.x];
+}
+
+// ---- two launches per chunk (variant 1) ----------------------------------------------------------------
+template <bool REV, int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_cols(const float2 *__restrict__ in, float2 *__restrict__ ws,
+                                                               const float2 *__restrict__ tw_1024)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + kPlaneBytes);
+    float2 *qtab = w1k + 1024;
+    stage_w1k(w1k, tw_1024);
+    __syncthreads();
+    const uint32_t tile = blockIdx.x % kTiles;
+    const uint64_t xform = blockIdx.x / kTiles;
+    cols_tile<REV, MODE, LAYOUT, true>(in + xform * (1ull << 20), ws + xform * (1ull << 20), tile, plane, w1k, qtab);
+}
+
+template <bool REV, int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__restrict__ ws, float2 *__restrict__ out,
+                                                               const float2 *__restrict__ tw_1024, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + kPlaneBytes);
+    stage_w1k(w1k, tw_1024);
+    __syncthreads();
+    const uint32_t tile = blockIdx.x % kTiles;
+    const uint64_t xform = blockIdx.x / kTiles;
+    rows_tile<REV, MODE, LAYOUT, true>(ws + xform * (1ull << 20), out + xform * (1ull << 20), tile, plane, w1k, scale);
+}
+
+// ---- one persistent launch per batch ----------------------------------------------------------------------
+// Synchronisation words (zeroed by the host before every launch, a block of their own):
+//   sync[0] ticket counter    sync[1] abort flag (a bounded spin gave up: results invalid, every workgroup drains)
+//   sync[4 + t]          pass-1 tiles of transform t that have published their output   (target kTiles)
+//   sync[4 + count + t]  pass-2 tiles of transform t that have finished reading it      (target kTiles)
+// Ticket order: step s = ticket / 128 holds the 64 pass-1 tiles of transform s followed by the 64 pass-2 tiles of
+// transform s - lag; a transform's intermediate lives in ring slot t % ring.  A workgroup only ever waits for work
+// of LOWER tickets (pass 2 of t waits for pass 1 of t: lag >= 0; pass 1 of t waits for pass 2 of t - ring:
+// ring > lag), and a ticket is held by a running workgroup or done -- so the grid drains whatever its size and
+// whatever the dispatch order.  Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores, every wave
+// drains them, workgroup barrier, ONE lane: agent-scope release fence + wait + relaxed counter add; the consumer's ONE
+// lane polls relaxed, then ONE agent-scope acquire + wait, workgroup barrier, plain (vector) loads.
+struct fused_args {
+    float2 *data;       // count x 2^20, in place
+    float2 *ws;         // ring x 2^20
+    const float2 *tw_1024;
+    unsigned *sync;
+    uint32_t count, ring, lag;
+    float scale;
+    unsigned long long spin_limit; // wall_clock64 ticks (100 MHz) a poll may take before it gives up
+};
+
+__device__ __forceinline__ unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ONE lane waits until *word >= target (or the launch is aborted); returns false when it gave up
+__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned long long limit)
+{
+    if (ld_relaxed(word) >= target)
+        return true;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(4);
+        if (ld_relaxed(word) >= target)
+            return true;
+        if (ld_relaxed(abort_flag) != 0)
+            return false;
+        if (wall_clock64() - t0 > limit) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+template <bool REV, int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + kPlaneBytes);
+    float2 *qtab = w1k + 1024;
+    unsigned *mail = reinterpret_cast<unsigned *>(qtab + 32 * kTile); // [0] this item's ticket, [1] go / abort
+
+    unsigned *const ticket_ctr = a.sync, *const abort_flag = a.sync + 1;
+    unsigned *const done1 = a.sync + 4, *const done2 = a.sync + 4 + a.count;
+    const unsigned n_tickets = (a.count + a.lag) * (2 * kTiles);
+
+    stage_w1k(w1k, a.tw_1024);
+    unsigned next = 0;
+    if (threadIdx.x == 0)
+        next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    for (;;) {
+        // ---- this item's ticket (drawn one item ahead, so the atomic's latency hides behind the previous tile)
+        if (threadIdx.x == 0)
+            mail[0] = next;
+        __syncthreads(); // also: every wave has finished the previous item (plane / qtab are free)
+        const unsigned ticket = mail[0];
+        if (ticket >= n_tickets)
+            break;
+        if (threadIdx.x == 0)
+            next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned step = ticket / (2 * kTiles), sub = ticket % (2 * kTiles);
+        const bool first = sub < kTiles;
+        const unsigned xf = first ? step : step - a.lag; // wraps for the leading pass-2 slots: filtered below
+        if (xf >= a.count)
+            continue; // ramp-up / ramp-down slot without work (uniform)
+        const unsigned tile = first ? sub : sub - kTiles;
+        float2 *const ws_x = a.ws + (size_t)(xf % a.ring) * (1ull << 20);
+        float2 *const data_x = a.data + (size_t)xf * (1ull << 20);
+
+        // ---- wait for what this item depends on (ONE lane polls; ONE acquire for the workgroup)
+        unsigned *wait_word = nullptr;
+        if (!first)
+            wait_word = done1 + xf; // the whole intermediate of this transform
+        else if (xf >= a.ring)
+            wait_word = done2 + (xf - a.ring); // the ring slot's previous tenant has been read
+        if (wait_word) {
+            if (threadIdx.x == 0) {
+                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.spin_limit);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                mail[1] = ok ? 1u : 0u;
+            }
+            __syncthreads();
+            if (mail[1] == 0u)
+                break; // aborted: drain (uniform)
+        }
+
+        if (first)
+            cols_tile<REV, MODE, LAYOUT, true>(data_x, ws_x, tile, plane, w1k, qtab);
+        else
+            rows_tile<REV, MODE, LAYOUT, true>(ws_x, data_x, tile, plane, w1k, a.scale);
+
+        // ---- publish: pass 1 hands its output to other workgroups; pass 2 frees the ring slot, and its reads
+        // of the slot must be complete (they are: the values were consumed) before the slot's next tenant stores
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(done1 + xf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            __syncthreads(); // every wave's loads of the slot have returned (their values fed the butterflies)
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(done2 + xf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+} // namespace fft1m
+} // namespace sdsp_hip

@@ -65,10 +65,8 @@ struct fft4096_args {
     uint64_t batch;
     float scale;
     int reverse;
-    int pair = 0; // radix-2 sibling: two consecutive transforms per workgroup (measured slower: 67.7 vs 76.7 %)
 };
 int launch_fft4096_r4_f32(const fft4096_args &a, int variant, void *stream);
-const char *fft4096_kernel_name(int variant);
 int fft4096_num_variants();
 int launch_fft4096_r2_f32(const fft4096_args &a, void *stream); // tuned radix-2 sibling
 // fused y = IFFT(FFT(x) .* h), n = 4096, f32; tw = FORWARD thread-twiddle table
@@ -113,7 +111,21 @@ struct fft1m_args {
     float scale;
     int reverse;
 };
-int launch_fft1m_r2_f32(const fft1m_args &a, void *stream);
+int launch_fft1m_pass(const fft1m_args &a, int which, void *stream); // which = 1 columns pass, 2 rows pass (variant 1)
+// the default schedule: ONE persistent launch over `count` transforms (fft1m_kernels.h)
+struct fft1m_fused_args {
+    void *data;          // count x 2^20 complex, in place
+    void *workspace;     // ring x 2^20 complex
+    const void *tw_1024; // W_1024^j
+    void *sync;          // fft1m_sync_bytes(count) bytes of device memory (zeroed by the launcher)
+    uint64_t count;
+    uint32_t ring, lag;  // intermediate ring slots; steps pass 2 trails pass 1 (lag < ring)
+    int layout;          // 0 rows, 1 blocked (fft1m_kernels.h: ws_layout)
+    float scale;
+    int reverse;
+};
+size_t fft1m_sync_bytes(uint64_t count);
+int launch_fft1m_fused(const fft1m_fused_args &a, void *stream);
 
 // ------------------------------------------------------------------------------------------
 // IIR bank
