@@ -152,7 +152,20 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
     return SDSP_HIP_OK;
 }
 
-constexpr uint64_t kFft1mRing = 8;        // intermediate ring of the N = 2^20 persistent kernel (transforms)
+// Shape of the N = 2^20 persistent kernel for a workspace of `slots` transforms: independent ticket queues, ring slots
+// per queue, and how many of a queue's ticket steps pass 2 trails pass 1 (lag < ring).
+void fft1m_shape(uint64_t slots, uint32_t *queues, uint32_t *ring, uint32_t *lag)
+{
+    if (slots >= 24) {
+        *queues = 8, *ring = 3, *lag = 1;
+    } else if (slots >= 16) {
+        *queues = 8, *ring = 2, *lag = 1;
+    } else {
+        *queues = 1;
+        *ring = (uint32_t)std::min<uint64_t>(slots, 8);
+        *lag = *ring > 2 ? *ring - 2 : *ring - 1;
+    }
+}
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
@@ -353,8 +366,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         }
         // default: ONE persistent launch; pass 2 of transform t runs `lag` ticket steps behind pass 1, the
         // intermediate lives in a ring of `ring` transforms (fft1m_kernels.h).  variant 2: row-major intermediate.
-        const uint32_t ring = (uint32_t)std::min<uint64_t>(p->ws_batch, kFft1mRing);
-        const uint32_t lag = ring > 2 ? ring - 2 : ring - 1;
+        uint32_t queues, ring, lag;
+        fft1m_shape(p->ws_batch, &queues, &ring, &lag);
         for (uint64_t done = 0; done < batch; done += p->sync_count) {
             fft1m_fused_args a;
             a.data = reinterpret_cast<char *>(data) + done * N * 8;
@@ -364,6 +377,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.count = std::min<uint64_t>(p->sync_count, batch - done);
             a.ring = ring;
             a.lag = lag;
+            a.queues = queues;
             a.layout = variant == 2 ? 0 : 1;
             a.scale = scale;
             a.reverse = rev;
@@ -616,7 +630,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
-            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count));
+            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count, 8));
             if (e != hipSuccess)
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft1m counters hipMalloc: ") + hipGetErrorString(e));
         }

@@ -84,10 +84,12 @@ template <bool REV, int LAYOUT> int launch_fused_t(const fft1m_fused_args &a, hi
     k.count = (uint32_t)a.count;
     k.ring = a.ring;
     k.lag = a.lag;
+    k.queues = a.queues;
+    k.flags = 0;
+    k.sleep = 0;
     k.scale = a.scale;
     k.spin_limit = 200000000ull; // 2 s at 100 MHz: far beyond any real wait; a lost hand-off aborts instead of hanging
-    const uint64_t tickets = (uint64_t)(a.count + a.lag) * (2 * kTiles);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)resident_grid(), tickets);
+    const uint32_t grid = (uint32_t)resident_grid();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, s, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -96,7 +98,7 @@ template <bool REV, int LAYOUT> int launch_fused_t(const fft1m_fused_args &a, hi
 }
 } // namespace
 
-size_t fft1m_sync_bytes(uint64_t count) { return ((4 + 2 * count) * sizeof(unsigned) + 15) & ~(size_t)15; }
+size_t fft1m_sync_bytes(uint64_t count, uint32_t queues) { return fused_sync_words((uint32_t)count, queues) * sizeof(unsigned); }
 
 // One persistent launch over `count` transforms (the plan's default).  a.sync: fft1m_sync_bytes(count) bytes of device
 // memory, zeroed here on the stream before the launch (Guideline 16: re-initialise every call).
@@ -104,10 +106,10 @@ int launch_fft1m_fused(const fft1m_fused_args &a, void *stream)
 {
     if (a.count == 0)
         return SDSP_HIP_OK;
-    if (a.ring == 0 || a.lag >= a.ring || a.count > 0x00ffffffu)
-        return fail(SDSP_HIP_ERR_INVALID_ARG, "fft1m fused: need lag < ring and a sane count");
+    if (a.ring == 0 || a.lag >= a.ring || a.queues == 0 || a.count > 0x00ffffffu)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "fft1m fused: need lag < ring, queues > 0 and a sane count");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(a.sync, 0, fft1m_sync_bytes(a.count), s);
+    hipError_t e = hipMemsetAsync(a.sync, 0, fft1m_sync_bytes(a.count, a.queues), s);
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft1m sync memset: ") + hipGetErrorString(e));
     if (a.layout == WS_BLOCKED)

@@ -274,45 +274,92 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
     rows_tile<REV, MODE, LAYOUT, true>(ws + xform * (1ull << 20), out + xform * (1ull << 20), tile, plane, w1k, scale);
 }
 
+// ---- two passes of DIFFERENT chunks in one launch (software pipelining across launches) -----------------------------
+// Launch i runs pass 1 of chunk i (HBM read, intermediate write) and pass 2 of chunk i - 1 (intermediate read, HBM
+// write) side by side: odd / even workgroups alternate between the two, so every CU holds one of each and the two kinds
+// of traffic overlap all the time.  All dependencies cross a kernel boundary (pass 2 of a chunk runs one launch after its
+// pass 1; the intermediate is double-buffered), so there is no in-kernel synchronisation at all.
+template <bool REV, int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_mixed(const float2 *in1, float2 *ws1, uint32_t n1, const float2 *ws2,
+                                                                float2 *out2, uint32_t n2, const float2 *__restrict__ tw_1024,
+                                                                float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft1m_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + kPlaneBytes);
+    float2 *qtab = w1k + 1024;
+    stage_w1k(w1k, tw_1024);
+    __syncthreads();
+    const uint32_t t1 = n1 * kTiles, t2 = n2 * kTiles, both = 2 * (t1 < t2 ? t1 : t2);
+    const uint32_t b = blockIdx.x;
+    bool first;
+    uint32_t item;
+    if (b < both) {
+        first = (b & 1) == 0;
+        item = b >> 1;
+    } else {
+        first = t1 > t2;
+        item = b - both / 2;
+    }
+    const uint32_t tile = item % kTiles;
+    const size_t xoff = (size_t)(item / kTiles) << 20;
+    if (first)
+        cols_tile<REV, MODE, LAYOUT, true>(in1 + xoff, ws1 + xoff, tile, plane, w1k, qtab);
+    else
+        rows_tile<REV, MODE, LAYOUT, true>(ws2 + xoff, out2 + xoff, tile, plane, w1k, scale);
+}
+
 // ---- one persistent launch per batch ----------------------------------------------------------------------
-// Synchronisation words (zeroed by the host before every launch, a block of their own):
-//   sync[0] ticket counter    sync[1] abort flag (a bounded spin gave up: results invalid, every workgroup drains)
-//   sync[4 + t]          pass-1 tiles of transform t that have published their output   (target kTiles)
-//   sync[4 + count + t]  pass-2 tiles of transform t that have finished reading it      (target kTiles)
-// Ticket order: step s = ticket / 128 holds the 64 pass-1 tiles of transform s followed by the 64 pass-2 tiles of
-// transform s - lag; a transform's intermediate lives in ring slot t % ring.  A workgroup only ever waits for work
-// of LOWER tickets (pass 2 of t waits for pass 1 of t: lag >= 0; pass 1 of t waits for pass 2 of t - ring:
-// ring > lag), and a ticket is held by a running workgroup or done -- so the grid drains whatever its size and
-// whatever the dispatch order.  Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores, every wave
-// drains them, workgroup barrier, ONE lane: agent-scope release fence + wait + relaxed counter add; the consumer's ONE
-// lane polls relaxed, then ONE agent-scope acquire + wait, workgroup barrier, plain (vector) loads.
+// Workgroups are bound to one of `queues` independent queues (blockIdx % queues); queue q owns the transforms
+// t = q, q + queues, ... and its own ticket counter, so the ticket atomics of the whole grid do not serialise on one
+// address.  Within a queue, ticket step s holds the 64 pass-1 tiles of the queue's s-th transform followed by the 64
+// pass-2 tiles of its (s - lag)-th; a transform's intermediate lives in slot (q * ring + i % ring) of the workspace.
+// A workgroup only ever waits for work of LOWER tickets of its own queue (pass 2 of i waits for pass 1 of i: lag >= 0;
+// pass 1 of i waits for pass 2 of i - ring: ring > lag), and a ticket is held by a running workgroup or done -- so the
+// grid drains whatever its size and whatever the dispatch order.
+// Synchronisation words (zeroed by the host before every launch), every hot word on a line of its own:
+//   sync[32 q]                          ticket counter of queue q
+//   sync[32 queues]                     abort flag (a bounded spin gave up: results invalid, every workgroup drains)
+//   sync[32 (queues + 1) + 32 t]        pass-1 tiles of transform t that have published their output   (target kTiles)
+//   sync[32 (queues + 1) + 32 t + 16]   pass-2 tiles of transform t that have finished reading it      (target kTiles)
+// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores, every wave drains them, workgroup barrier, ONE
+// lane: agent-scope release fence + wait + relaxed counter add; the consumer's ONE lane polls relaxed, then ONE
+// agent-scope acquire + wait, workgroup barrier, plain (vector) loads.
 struct fused_args {
     float2 *data;       // count x 2^20, in place
-    float2 *ws;         // ring x 2^20
+    float2 *ws;         // queues x ring x 2^20
     const float2 *tw_1024;
     unsigned *sync;
-    uint32_t count, ring, lag;
+    uint32_t count, ring, lag, queues;
+    uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence (timing experiments; results then invalid)
+    uint32_t sleep;     // s_sleep argument of the polls is fixed; this many extra sleeps per poll iteration
     float scale;
     unsigned long long spin_limit; // wall_clock64 ticks (100 MHz) a poll may take before it gives up
 };
+__host__ __device__ constexpr size_t fused_sync_words(uint32_t count, uint32_t queues) { return 32ull * (queues + 1) + 32ull * count; }
 
 __device__ __forceinline__ unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ONE lane waits until *word >= target (or the launch is aborted); returns false when it gave up
-__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned long long limit)
+__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned long long limit,
+                                         uint32_t extra_sleep)
 {
     if (ld_relaxed(word) >= target)
         return true;
     const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        __builtin_amdgcn_s_sleep(4);
+    for (unsigned it = 0;; it++) {
+        __builtin_amdgcn_s_sleep(8);
+        for (uint32_t i = 0; i < extra_sleep; i++)
+            __builtin_amdgcn_s_sleep(8);
         if (ld_relaxed(word) >= target)
             return true;
-        if (ld_relaxed(abort_flag) != 0)
-            return false;
-        if (wall_clock64() - t0 > limit) {
-            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
+        if ((it & 31) == 31) { // the give-up checks are rare: they must not add traffic to the hot words
+            if (ld_relaxed(abort_flag) != 0)
+                return false;
+            if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
         }
     }
 }
@@ -326,9 +373,13 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
     float2 *qtab = w1k + 1024;
     unsigned *mail = reinterpret_cast<unsigned *>(qtab + 32 * kTile); // [0] this item's ticket, [1] go / abort
 
-    unsigned *const ticket_ctr = a.sync, *const abort_flag = a.sync + 1;
-    unsigned *const done1 = a.sync + 4, *const done2 = a.sync + 4 + a.count;
-    const unsigned n_tickets = (a.count + a.lag) * (2 * kTiles);
+    const uint32_t q = blockIdx.x % a.queues;
+    if (q >= a.count)
+        return;
+    const uint32_t n_q = (a.count - q + a.queues - 1) / a.queues; // transforms of this queue
+    unsigned *const ticket_ctr = a.sync + 32 * q, *const abort_flag = a.sync + 32 * a.queues;
+    unsigned *const done = a.sync + 32 * (a.queues + 1);
+    const unsigned n_tickets = (n_q + a.lag) * (2 * kTiles);
 
     stage_w1k(w1k, a.tw_1024);
     unsigned next = 0;
@@ -347,24 +398,27 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
             next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned step = ticket / (2 * kTiles), sub = ticket % (2 * kTiles);
         const bool first = sub < kTiles;
-        const unsigned xf = first ? step : step - a.lag; // wraps for the leading pass-2 slots: filtered below
-        if (xf >= a.count)
+        const unsigned i = first ? step : step - a.lag; // wraps for the leading pass-2 slots: filtered below
+        if (i >= n_q)
             continue; // ramp-up / ramp-down slot without work (uniform)
         const unsigned tile = first ? sub : sub - kTiles;
-        float2 *const ws_x = a.ws + (size_t)(xf % a.ring) * (1ull << 20);
+        const unsigned xf = q + i * a.queues;
+        float2 *const ws_x = a.ws + (size_t)(q * a.ring + i % a.ring) * (1ull << 20);
         float2 *const data_x = a.data + (size_t)xf * (1ull << 20);
 
         // ---- wait for what this item depends on (ONE lane polls; ONE acquire for the workgroup)
         unsigned *wait_word = nullptr;
         if (!first)
-            wait_word = done1 + xf; // the whole intermediate of this transform
-        else if (xf >= a.ring)
-            wait_word = done2 + (xf - a.ring); // the ring slot's previous tenant has been read
+            wait_word = done + 32 * xf; // the whole intermediate of this transform
+        else if (i >= a.ring)
+            wait_word = done + 32 * (xf - a.ring * a.queues) + 16; // the ring slot's previous tenant has been read
         if (wait_word) {
             if (threadIdx.x == 0) {
-                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.spin_limit);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.spin_limit, a.sleep);
+                if (!(a.flags & 2u)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 mail[1] = ok ? 1u : 0u;
             }
             __syncthreads();
@@ -383,14 +437,16 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
             __syncthreads();
             if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(done1 + xf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(a.flags & 1u)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_fetch_add(done + 32 * xf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             __syncthreads(); // every wave's loads of the slot have returned (their values fed the butterflies)
             if (threadIdx.x == 0)
-                __hip_atomic_fetch_add(done2 + xf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(done + 32 * xf + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

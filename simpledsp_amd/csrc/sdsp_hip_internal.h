@@ -119,12 +119,13 @@ struct fft1m_fused_args {
     const void *tw_1024; // W_1024^j
     void *sync;          // fft1m_sync_bytes(count) bytes of device memory (zeroed by the launcher)
     uint64_t count;
-    uint32_t ring, lag;  // intermediate ring slots; steps pass 2 trails pass 1 (lag < ring)
+    uint32_t ring, lag;  // intermediate ring slots per queue; steps pass 2 trails pass 1 (lag < ring)
+    uint32_t queues;     // independent ticket queues (workspace holds queues x ring transforms)
     int layout;          // 0 rows, 1 blocked (fft1m_kernels.h: ws_layout)
     float scale;
     int reverse;
 };
-size_t fft1m_sync_bytes(uint64_t count);
+size_t fft1m_sync_bytes(uint64_t count, uint32_t queues);
 int launch_fft1m_fused(const fft1m_fused_args &a, void *stream);
 
 // ------------------------------------------------------------------------------------------

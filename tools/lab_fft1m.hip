@@ -58,10 +58,12 @@ template <bool REV, int MODE, int LAYOUT> static void two_launch(float2 *data, u
     }
 }
 
-template <bool REV, int MODE, int LAYOUT> static void fused(float2 *data, uint32_t batch, uint32_t ring, uint32_t lag, uint32_t per_cu)
+static uint32_t g_flags = 0, g_sleep = 0, g_last_queues = 1;
+template <bool REV, int MODE, int LAYOUT>
+static void fused(float2 *data, uint32_t batch, uint32_t ring, uint32_t lag, uint32_t per_cu, uint32_t queues = 1)
 {
     set_lds(sdsp_fft1m_fused<REV, MODE, LAYOUT>);
-    CK(hipMemsetAsync(g_sync, 0, ((4 + 2 * (size_t)batch) * 4 + 15) & ~(size_t)15, 0));
+    CK(hipMemsetAsync(g_sync, 0, fused_sync_words(batch, queues) * 4, 0));
     fused_args a;
     a.data = data;
     a.ws = g_ws;
@@ -70,16 +72,39 @@ template <bool REV, int MODE, int LAYOUT> static void fused(float2 *data, uint32
     a.count = batch;
     a.ring = ring;
     a.lag = lag;
+    a.queues = queues;
+    g_last_queues = queues;
+    a.flags = g_flags;
+    a.sleep = g_sleep;
     a.scale = 1.0f / 1048576.0f;
     a.spin_limit = 100000000ull; // 1 s
     hipLaunchKernelGGL((sdsp_fft1m_fused<REV, MODE, LAYOUT>), dim3(per_cu * g_cus), dim3(kThreads), kLdsBytes, 0, a);
 }
 
+// software-pipelined launches: launch i = pass 1 of chunk i + pass 2 of chunk i - 1 (double-buffered intermediate)
+template <bool REV, int MODE, int LAYOUT> static void mixed(float2 *data, uint32_t batch, uint32_t chunk)
+{
+    set_lds(sdsp_fft1m_mixed<REV, MODE, LAYOUT>);
+    const uint32_t n_chunks = (batch + chunk - 1) / chunk;
+    for (uint32_t i = 0; i <= n_chunks; i++) {
+        const uint32_t n1 = i < n_chunks ? std::min(chunk, batch - i * chunk) : 0;
+        const uint32_t n2 = i > 0 ? std::min(chunk, batch - (i - 1) * chunk) : 0;
+        float2 *ws1 = g_ws + (size_t)(i & 1) * chunk * (1u << 20);
+        float2 *ws2 = g_ws + (size_t)((i + 1) & 1) * chunk * (1u << 20);
+        float2 *d1 = data + (size_t)i * chunk * (1u << 20);
+        float2 *d2 = i > 0 ? data + (size_t)(i - 1) * chunk * (1u << 20) : data;
+        hipLaunchKernelGGL((sdsp_fft1m_mixed<REV, MODE, LAYOUT>), dim3((n1 + n2) * kTiles), dim3(kThreads), kLdsBytes, 0, d1, ws1, n1,
+                           ws2, d2, n2, g_tw, 1.0f / 1048576.0f);
+    }
+}
+
 static unsigned read_abort()
 {
     unsigned w[4];
-    CK(hipMemcpy(w, g_sync, sizeof(w), hipMemcpyDeviceToHost));
-    return w[1];
+    (void)w;
+    unsigned v = 0;
+    CK(hipMemcpy(&v, g_sync + 32 * g_last_queues, 4, hipMemcpyDeviceToHost));
+    return v;
 }
 
 // time `pairs` forward+reverse pairs of `run(rev)`; returns ms per call
@@ -114,10 +139,13 @@ static void report(const char *what, double ms)
     std::fflush(stdout);
 }
 
-template <int MODE, int LAYOUT> static void sweep(const char *mode_name, const char *layout_name)
+struct shape {
+    uint32_t queues, ring, lag, per_cu;
+};
+template <int MODE, int LAYOUT> static void sweep(const char *mode_name, const char *layout_name, bool quick)
 {
-    char buf[160];
-    for (uint32_t chunk : { 32u, 16u, 8u }) {
+    char buf[200];
+    for (uint32_t chunk : { 32u }) {
         std::snprintf(buf, sizeof buf, "%s %s two launches per chunk of %u", mode_name, layout_name, chunk);
         report(buf, time_it([&](bool rev) {
                    if (rev)
@@ -126,20 +154,37 @@ template <int MODE, int LAYOUT> static void sweep(const char *mode_name, const c
                        two_launch<false, MODE, LAYOUT>(g_data, g_batch, chunk);
                }));
     }
-    const uint32_t rl[][2] = { { 3, 2 }, { 4, 2 }, { 6, 4 }, { 8, 6 }, { 8, 4 }, { 12, 8 }, { 16, 12 }, { 32, 24 } };
-    for (auto &p : rl) {
-        for (uint32_t per_cu : { 2u }) {
-            std::snprintf(buf, sizeof buf, "%s %s persistent ring %u lag %u, %u wg/CU", mode_name, layout_name, p[0], p[1], per_cu);
+    for (uint32_t chunk : { 4u, 8u, 12u, 16u }) {
+        std::snprintf(buf, sizeof buf, "%s %s pipelined launches, chunk %u", mode_name, layout_name, chunk);
+        report(buf, time_it([&](bool rev) {
+                   if (rev)
+                       mixed<true, MODE, LAYOUT>(g_data, g_batch, chunk);
+                   else
+                       mixed<false, MODE, LAYOUT>(g_data, g_batch, chunk);
+               }));
+    }
+    const shape shapes[] = { { 1, 8, 4, 2 },  { 1, 16, 12, 2 }, { 1, 32, 24, 2 }, { 8, 2, 1, 2 }, { 8, 3, 1, 2 },
+                             { 8, 4, 2, 2 },  { 16, 2, 1, 2 },  { 4, 4, 2, 2 },   { 4, 8, 4, 2 }, { 2, 8, 4, 2 } };
+    for (uint32_t flags : { 0u, 3u }) {
+        if (flags && MODE == MODE_FFT)
+            continue; // the no-fence runs are timing experiments on the data movers only
+        for (auto &sh : shapes) {
+            if (quick && !(sh.queues == 8 && sh.ring == 3) && !(sh.queues == 1 && sh.ring == 32))
+                continue;
+            g_flags = flags;
+            std::snprintf(buf, sizeof buf, "%s %s persistent queues %u ring %u lag %u%s", mode_name, layout_name, sh.queues, sh.ring,
+                          sh.lag, flags ? " NO FENCES" : "");
             report(buf, time_it([&](bool rev) {
                        if (rev)
-                           fused<true, MODE, LAYOUT>(g_data, g_batch, p[0], p[1], per_cu);
+                           fused<true, MODE, LAYOUT>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
                        else
-                           fused<false, MODE, LAYOUT>(g_data, g_batch, p[0], p[1], per_cu);
+                           fused<false, MODE, LAYOUT>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
                    }));
             if (read_abort())
                 std::printf("   ^^^ ABORTED (a bounded spin gave up)\n");
         }
     }
+    g_flags = 0;
 }
 
 int main(int argc, char **argv)
@@ -155,7 +200,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&g_ref, n * 8));
     CK(hipMalloc(&g_ws, (size_t)32 << 23));
     CK(hipMalloc(&g_tw, 1024 * 8));
-    CK(hipMalloc(&g_sync, (4 + 2 * (size_t)g_batch) * 4 + 16));
+    CK(hipMalloc(&g_sync, fused_sync_words(g_batch, 16) * 4));
     std::vector<float2> tw(1024);
     for (int j = 0; j < 1024; j++) {
         const double a = -2.0 * M_PI * j / 1024.0;
@@ -163,46 +208,73 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(g_tw, tw.data(), 1024 * 8, hipMemcpyHostToDevice));
 
-    // ---- correctness of the persistent schedule: bit-identical to the two-launch schedule, several ring shapes,
-    // repeated (a lost or early hand-off shows as a mismatch)
+    // ---- correctness of the persistent and the pipelined schedules: bit-identical to the two-launch schedule, several
+    // shapes, repeated (a lost or early hand-off shows as a mismatch)
     int bad_total = 0;
-    for (int rep = 0; rep < 3; rep++) {
+    std::vector<float2> ha(1 << 20), hb(1 << 20);
+    auto compare = [&](const char *what) {
+        const unsigned ab = read_abort();
+        size_t bad = 0;
+        int first_bad = -1, n_bad_x = 0;
+        for (uint32_t x = 0; x < g_batch; x += (g_batch > 32 ? g_batch / 32 : 1)) {
+            CK(hipMemcpy(ha.data(), g_data + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb.data(), g_ref + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
+            size_t here = 0;
+            for (size_t i = 0; i < ha.size(); i++)
+                here += (ha[i].x != hb[i].x) || (ha[i].y != hb[i].y);
+            if (here) {
+                n_bad_x++;
+                if (first_bad < 0)
+                    first_bad = (int)x;
+            }
+            bad += here;
+        }
+        std::printf("check %-48s %zu mismatching elements in %d transforms (first: %d)%s\n", what, bad, n_bad_x, first_bad,
+                    ab ? "  ABORTED" : "");
+        std::fflush(stdout);
+        bad_total += bad != 0 || ab;
+    };
+    for (int rep = 0; rep < 2; rep++) {
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_ref, n, 1234u + rep);
         two_launch<false, MODE_FFT, WS_ROWS>(g_ref, g_batch, 32);
         CK(hipDeviceSynchronize());
-        const uint32_t rl[][2] = { { 1, 0 }, { 2, 1 }, { 4, 2 }, { 8, 6 }, { 32, 24 } };
-        for (auto &p : rl)
-            for (int layout = 0; layout < 2; layout++) {
+        const shape shapes[] = { { 1, 32, 24, 2 }, { 1, 1, 0, 2 }, { 1, 2, 1, 2 }, { 1, 8, 4, 2 }, { 1, 32, 24, 2 },
+                                 { 8, 2, 1, 2 },   { 8, 3, 1, 2 }, { 16, 2, 1, 2 }, { 4, 8, 4, 2 }, { 8, 4, 3, 3 } };
+        char what[160];
+        for (auto &sh : shapes)
+            for (int layout = 1; layout >= 0; layout--) {
                 hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 1234u + rep);
                 if (layout)
-                    fused<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, p[0], p[1], 2);
+                    fused<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
                 else
-                    fused<false, MODE_FFT, WS_ROWS>(g_data, g_batch, p[0], p[1], 2);
+                    fused<false, MODE_FFT, WS_ROWS>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
                 CK(hipDeviceSynchronize());
-                const unsigned ab = read_abort();
-                // compare on the host in slices
-                size_t bad = 0;
-                std::vector<float2> ha(1 << 20), hb(1 << 20);
-                for (uint32_t x = 0; x < g_batch; x += (g_batch > 16 ? g_batch / 16 : 1)) {
-                    CK(hipMemcpy(ha.data(), g_data + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
-                    CK(hipMemcpy(hb.data(), g_ref + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
-                    for (size_t i = 0; i < ha.size(); i++)
-                        bad += (ha[i].x != hb[i].x) || (ha[i].y != hb[i].y);
-                }
-                std::printf("check rep %d ring %2u lag %2u layout %d: %zu mismatching elements%s\n", rep, p[0], p[1], layout, bad,
-                            ab ? "  ABORTED" : "");
-                bad_total += bad != 0 || ab;
+                std::snprintf(what, sizeof what, "rep %d persistent q %u ring %u lag %u wg/CU %u layout %d:", rep, sh.queues, sh.ring,
+                              sh.lag, sh.per_cu, layout);
+                compare(what);
+            }
+        for (uint32_t chunk : { 4u, 8u, 16u })
+            for (int layout = 1; layout >= 0; layout--) {
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 1234u + rep);
+                if (layout)
+                    mixed<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, chunk);
+                else
+                    mixed<false, MODE_FFT, WS_ROWS>(g_data, g_batch, chunk);
+                CK(hipDeviceSynchronize());
+                g_last_queues = 1;
+                CK(hipMemset(g_sync, 0, 256));
+                std::snprintf(what, sizeof what, "rep %d pipelined launches chunk %u layout %d:", rep, chunk, layout);
+                compare(what);
             }
     }
     std::printf("correctness: %s\n", bad_total ? "FAILED" : "ok");
     std::fflush(stdout);
 
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 99u);
-    sweep<MODE_FFT, WS_ROWS>("fft ", "rows   ");
-    sweep<MODE_FFT, WS_BLOCKED>("fft ", "blocked");
+    sweep<MODE_FFT, WS_BLOCKED>("fft ", "blocked", false);
+    sweep<MODE_FFT, WS_ROWS>("fft ", "rows   ", true);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 99u);
-    sweep<MODE_MOVE, WS_ROWS>("move", "rows   ");
-    sweep<MODE_MOVE, WS_BLOCKED>("move", "blocked");
-    sweep<MODE_HBM_ONLY, WS_ROWS>("hbm-only", "");
+    sweep<MODE_MOVE, WS_BLOCKED>("move", "blocked", false);
+    sweep<MODE_HBM_ONLY, WS_BLOCKED>("hbm-only", "", false);
     return bad_total ? 1 : 0;
 }
