@@ -152,20 +152,7 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
     return SDSP_HIP_OK;
 }
 
-// Shape of the N = 2^20 persistent kernel for a workspace of `slots` transforms: independent ticket queues, ring slots
-// per queue, and how many of a queue's ticket steps pass 2 trails pass 1 (lag < ring).
-void fft1m_shape(uint64_t slots, uint32_t *queues, uint32_t *ring, uint32_t *lag)
-{
-    if (slots >= 24) {
-        *queues = 8, *ring = 3, *lag = 1;
-    } else if (slots >= 16) {
-        *queues = 8, *ring = 2, *lag = 1;
-    } else {
-        *queues = 1;
-        *ring = (uint32_t)std::min<uint64_t>(slots, 8);
-        *lag = *ring > 2 ? *ring - 2 : *ring - 1;
-    }
-}
+constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
@@ -341,12 +328,11 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     if (int rc = ensure_workspace(p)) // every path below is multi-pass
         return rc;
 
-    if (p->path == PATH_FFT1M && variant < 3) {
+    if (p->path == PATH_FFT1M && variant < 2) {
         const uint64_t N = 1ull << 20;
         const float scale = (float)(1.0 / (double)N);
-        if (variant == 1) {
-            // round 1's schedule: two launches per chunk of <= 32 transforms, the chunk's intermediate matrices still
-            // (partly) in the 256 MiB Infinity Cache when pass 2 reads them
+        if (variant == 1 || p->ws_batch < kFft1mQueues * kFft1mRing) {
+            // two launches per chunk of <= 32 transforms (round 1's schedule; also what plans with a small workspace run)
             const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch));
             for (uint64_t done = 0; done < batch; done += chunk) {
                 fft1m_args a;
@@ -364,10 +350,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             }
             return SDSP_HIP_OK;
         }
-        // default: ONE persistent launch; pass 2 of transform t runs `lag` ticket steps behind pass 1, the
-        // intermediate lives in a ring of `ring` transforms (fft1m_kernels.h).  variant 2: row-major intermediate.
-        uint32_t queues, ring, lag;
-        fft1m_shape(p->ws_batch, &queues, &ring, &lag);
+        // default: ONE persistent launch (fft1m_kernels.h): eight ticket queues, per queue a ring of three intermediates,
+        // pass 2 of a queue's transform one ticket step behind its pass 1
         for (uint64_t done = 0; done < batch; done += p->sync_count) {
             fft1m_fused_args a;
             a.data = reinterpret_cast<char *>(data) + done * N * 8;
@@ -375,10 +359,9 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.tw_1024 = p->tw1;
             a.sync = p->sync;
             a.count = std::min<uint64_t>(p->sync_count, batch - done);
-            a.ring = ring;
-            a.lag = lag;
-            a.queues = queues;
-            a.layout = variant == 2 ? 0 : 1;
+            a.ring = (uint32_t)kFft1mRing;
+            a.lag = 1;
+            a.queues = (uint32_t)kFft1mQueues;
             a.scale = scale;
             a.reverse = rev;
             if (int rc = launch_fft1m_fused(a, stream))
@@ -625,12 +608,12 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->twiddle_bytes = ((uint64_t)n + p->n1 + p->n2) * esize(precision);
         pick_tile(precision, p->n1, 16, &p->cols1, &p->pitch1);
         pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
-        // the tuned 2^20 path keeps a ring of intermediates (8 for the persistent kernel, 32 for variant 1's chunks)
+        // the tuned 2^20 path keeps 24 intermediates for the persistent kernel (8 queues x 3) / 32 for variant 1's chunks
         p->ws_batch = p->path == PATH_FFT1M ? std::min<uint64_t>(p->max_batch, 32) : p->max_batch;
         p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
-            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count, 8));
+            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues));
             if (e != hipSuccess)
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft1m counters hipMalloc: ") + hipGetErrorString(e));
         }
@@ -862,8 +845,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     const char *name = "sdsp_fft_tile_kernel";
     if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants())
         name = "sdsp_fft4096_r4_f32";
-    if (p->path == PATH_FFT1M && p->variant < 3)
-        name = p->variant == 1 ? "sdsp_fft1m_cols+sdsp_fft1m_rows" : "sdsp_fft1m_fused";
+    if (p->path == PATH_FFT1M && p->variant < 2)
+        name = (p->variant == 1 || p->ws_batch < kFft1mQueues * kFft1mRing) ? "sdsp_fft1m_cols+sdsp_fft1m_rows" : "sdsp_fft1m_fused";
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";

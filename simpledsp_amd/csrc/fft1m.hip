@@ -26,24 +26,24 @@ int launch_fft1m_pass(const fft1m_args &a, int which, void *stream)
     float2 *ws = reinterpret_cast<float2 *>(a.workspace);
     const float2 *tw1k = reinterpret_cast<const float2 *>(a.tw_1024);
     static std::atomic<uint64_t> done[4];
-    const void *kerns[4] = { reinterpret_cast<const void *>(sdsp_fft1m_cols<false, MODE_FFT, WS_ROWS>),
-                             reinterpret_cast<const void *>(sdsp_fft1m_cols<true, MODE_FFT, WS_ROWS>),
-                             reinterpret_cast<const void *>(sdsp_fft1m_rows<false, MODE_FFT, WS_ROWS>),
-                             reinterpret_cast<const void *>(sdsp_fft1m_rows<true, MODE_FFT, WS_ROWS>) };
+    const void *kerns[4] = { reinterpret_cast<const void *>(sdsp_fft1m_cols<false, MODE_FFT, WS_BLOCKED>),
+                             reinterpret_cast<const void *>(sdsp_fft1m_cols<true, MODE_FFT, WS_BLOCKED>),
+                             reinterpret_cast<const void *>(sdsp_fft1m_rows<false, MODE_FFT, WS_BLOCKED>),
+                             reinterpret_cast<const void *>(sdsp_fft1m_rows<true, MODE_FFT, WS_BLOCKED>) };
     const int idx = (which == 1 ? 0 : 2) + (a.reverse ? 1 : 0);
     if (int rc = ensure_dynamic_lds(kerns[idx], kLdsBytes, done[idx]))
         return rc;
     const dim3 grid((uint32_t)blocks), block(kThreads);
     if (which == 1) {
         if (a.reverse)
-            hipLaunchKernelGGL((sdsp_fft1m_cols<true, MODE_FFT, WS_ROWS>), grid, block, kLdsBytes, s, in, ws, tw1k);
+            hipLaunchKernelGGL((sdsp_fft1m_cols<true, MODE_FFT, WS_BLOCKED>), grid, block, kLdsBytes, s, in, ws, tw1k);
         else
-            hipLaunchKernelGGL((sdsp_fft1m_cols<false, MODE_FFT, WS_ROWS>), grid, block, kLdsBytes, s, in, ws, tw1k);
+            hipLaunchKernelGGL((sdsp_fft1m_cols<false, MODE_FFT, WS_BLOCKED>), grid, block, kLdsBytes, s, in, ws, tw1k);
     } else {
         if (a.reverse)
-            hipLaunchKernelGGL((sdsp_fft1m_rows<true, MODE_FFT, WS_ROWS>), grid, block, kLdsBytes, s, ws, out, tw1k, a.scale);
+            hipLaunchKernelGGL((sdsp_fft1m_rows<true, MODE_FFT, WS_BLOCKED>), grid, block, kLdsBytes, s, ws, out, tw1k, a.scale);
         else
-            hipLaunchKernelGGL((sdsp_fft1m_rows<false, MODE_FFT, WS_ROWS>), grid, block, kLdsBytes, s, ws, out, tw1k, a.scale);
+            hipLaunchKernelGGL((sdsp_fft1m_rows<false, MODE_FFT, WS_BLOCKED>), grid, block, kLdsBytes, s, ws, out, tw1k, a.scale);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -112,8 +112,7 @@ int launch_fft1m_fused(const fft1m_fused_args &a, void *stream)
     hipError_t e = hipMemsetAsync(a.sync, 0, fft1m_sync_bytes(a.count, a.queues), s);
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft1m sync memset: ") + hipGetErrorString(e));
-    if (a.layout == WS_BLOCKED)
-        return a.reverse ? launch_fused_t<true, WS_BLOCKED>(a, s) : launch_fused_t<false, WS_BLOCKED>(a, s);
-    return a.reverse ? launch_fused_t<true, WS_ROWS>(a, s) : launch_fused_t<false, WS_ROWS>(a, s);
+    constexpr int kLayout = WS_BLOCKED | WS_SC1_STORES;
+    return a.reverse ? launch_fused_t<true, kLayout>(a, s) : launch_fused_t<false, kLayout>(a, s);
 }
 } // namespace sdsp_hip

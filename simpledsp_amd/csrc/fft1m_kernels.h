@@ -49,6 +49,36 @@ constexpr size_t kLdsBytes = kPlaneBytes + 1024 * sizeof(float2) + 32 * kTile * 
 // whole 8 KiB rows).  BLOCKED: [n2 / 16][k1][n2 % 16] -- a pass-1 tile's output is ONE contiguous 128 KiB block,
 // pass 2 gathers 2 KiB pieces (16 rows x 128 B) from each of the 64 blocks.
 enum ws_layout { WS_ROWS = 0, WS_BLOCKED = 1 };
+// lab only, OR-ed into LAYOUT: the intermediate is stored write-through (sc1: straight to the fabric, the line is not kept in
+// the XCD's L2) / loaded with sc1 (bypasses the CU's L1) -- the hand-off forms of cdna_hip_programming.md Guideline 16 that
+// need no release fence
+enum ws_access { WS_SC1_STORES = 2, WS_SC1_LOADS = 4, WS_STORE16 = 8 };
+// 16-byte write-through store: base (uniform) + 32-bit byte offset
+__device__ __forceinline__ void ws_store16_sc1(float2 *base, uint32_t byte_off, float2 lo, float2 hi)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = { lo.x, lo.y, hi.x, hi.y };
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+// the value the neighbouring lane (lane ^ 1) holds
+__device__ __forceinline__ float swap_lane1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void ws_store_sc1(float2 *p, float2 v)
+{
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &v, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ws_load_sc1(const float2 *p)
+{
+    const unsigned long long bits =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 v;
+    __builtin_memcpy(&v, &bits, 8);
+    return v;
+}
 // What a tile does.  MODE_FFT is the product.  The other two exist for tools/lab_fft1m.hip only: the same loads and
 // stores without the butterflies (MODE_MOVE), and without the intermediate's traffic either (MODE_HBM_ONLY: what the
 // HBM-facing halves of the two passes cost on their own).
@@ -126,14 +156,36 @@ __device__ __forceinline__ void cols_tile(const float2 *in_x, float2 *ws_x, uint
     const float2 *const qcol = qtab + c;
     float2 *dst_tile;
     uint32_t soff;
-    if constexpr (LAYOUT == WS_BLOCKED) {
+    if constexpr ((LAYOUT & 1) == WS_BLOCKED) {
         dst_tile = ws_x + (size_t)tile * (1024 * kTile); // [tile][k1][c]
         soff = (bu * 16 + c) * 8u;
     } else {
         dst_tile = ws_x + tile * kTile; // [k1][n2]
         soff = (bu * 1024 + c) * 8u;
     }
-    constexpr int kStep = LAYOUT == WS_BLOCKED ? 32 * 16 : 32 * 1024; // float2 elements between k1 and k1 + 32
+    constexpr int kStep = (LAYOUT & 1) == WS_BLOCKED ? 32 * 16 : 32 * 1024; // float2 elements between k1 and k1 + 32
+    if constexpr ((LAYOUT & WS_STORE16) != 0) {
+        // 16-byte stores: registers 2m and 2m+1 (rows k1 and k1 + 512 of the same column) of an even / odd lane pair are
+        // regrouped so that the even lane holds row k1 of columns (c, c+1) and the odd lane row k1 + 512 of (c-1, c)
+        static_assert((LAYOUT & 1) == WS_BLOCKED && (LAYOUT & WS_SC1_STORES), "16-byte stores: blocked layout, write-through");
+        const bool odd = (c & 1) != 0;
+        const uint32_t soff16 = (bu * 16 + (c & ~1u)) * 8u + (odd ? 16u * kStep * 8u : 0u); // brev5(2m+1) = brev5(2m) + 16
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            if ((m & 3) == 0)
+                __builtin_amdgcn_sched_barrier(0);
+            float2 a = x[2 * m], b = x[2 * m + 1];
+            if constexpr (MATH) {
+                a = cmul(a, cmul(pw, qcol[16 * (int)(__brev((uint32_t)(2 * m)) >> 27)]));
+                b = cmul(b, cmul(pw, qcol[16 * (int)(__brev((uint32_t)(2 * m + 1)) >> 27)]));
+            }
+            const float2 send = odd ? a : b;
+            const float2 recv = float2{ swap_lane1(send.x), swap_lane1(send.y) };
+            const float2 lo = odd ? recv : a, hi = odd ? b : recv;
+            ws_store16_sc1(dst_tile + kStep * (int)(__brev((uint32_t)(2 * m)) >> 27), soff16, lo, hi);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0) // keep at most 8 elements' table reads in flight (register budget)
@@ -144,6 +196,8 @@ __device__ __forceinline__ void cols_tile(const float2 *in_x, float2 *ws_x, uint
         if constexpr (MODE == MODE_HBM_ONLY) {
             if (v.x == 1.2345e-30f) // never true for the lab's data: keeps the loads alive without the stores
                 *at(dst_tile + kStep * (int)(__brev((uint32_t)k) >> 27), soff) = v;
+        } else if constexpr ((LAYOUT & WS_SC1_STORES) != 0) {
+            ws_store_sc1(at(dst_tile + kStep * (int)(__brev((uint32_t)k) >> 27), soff), v);
         } else {
             *at(dst_tile + kStep * (int)(__brev((uint32_t)k) >> 27), soff) = v;
         }
@@ -164,19 +218,19 @@ __device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uin
 #pragma unroll
         for (int k = 0; k < 32; k++)
             x[k] = float2{ (float)t, (float)k };
-    } else if constexpr (LAYOUT == WS_BLOCKED) {
+    } else if constexpr ((LAYOUT & 1) == WS_BLOCKED) {
         // element n2 = ua + 32k of row k1 = 16 tile + ra lives at [(n2 >> 4)][k1][n2 & 15]
         const float2 *src = ws_x + (size_t)tile * (kTile * kTile);
         const uint32_t aoff = ((ua >> 4) * (1024 * kTile) + ra * 16 + (ua & 15)) * 8u;
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            x[k] = *at(src + 2 * k * (1024 * kTile), aoff);
+            x[k] = (LAYOUT & WS_SC1_LOADS) ? ws_load_sc1(at(src + 2 * k * (1024 * kTile), aoff)) : *at(src + 2 * k * (1024 * kTile), aoff);
     } else {
         const float2 *src = ws_x + (size_t)tile * kTile * 1024;
         const uint32_t aoff = (ra * 1024 + ua) * 8u; // bytes
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            x[k] = *at(src + 32 * k, aoff);
+            x[k] = (LAYOUT & WS_SC1_LOADS) ? ws_load_sc1(at(src + 32 * k, aoff)) : *at(src + 32 * k, aoff);
     }
     // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
     const uint32_t rb = t & 15, ub = t >> 4;
@@ -322,16 +376,19 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_mixed(const float2 *in
 //   sync[32 queues]                     abort flag (a bounded spin gave up: results invalid, every workgroup drains)
 //   sync[32 (queues + 1) + 32 t]        pass-1 tiles of transform t that have published their output   (target kTiles)
 //   sync[32 (queues + 1) + 32 t + 16]   pass-2 tiles of transform t that have finished reading it      (target kTiles)
-// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores, every wave drains them, workgroup barrier, ONE
-// lane: agent-scope release fence + wait + relaxed counter add; the consumer's ONE lane polls relaxed, then ONE
-// agent-scope acquire + wait, workgroup barrier, plain (vector) loads.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, form R1): the intermediate is stored WRITE-THROUGH (sc1), every
+// storing wave drains its stores, workgroup barrier, ONE lane adds to the arrival counter (relaxed, agent scope); the
+// consumer's ONE lane polls relaxed, then ONE agent-scope acquire + wait, workgroup barrier, plain (vector) loads.  With
+// plain stores instead the publishing lane needs an agent-scope release fence (buffer_wbl2) in front of the add: correct
+// too, but each one writes back the XCD's whole L2 and costs the workgroup ~8 us -- 2.4 ms per 256 transforms against
+// 1.3 ms (tools/lab_fft1m.hip, profiles/r02_fft1m_lab.md).
 struct fused_args {
     float2 *data;       // count x 2^20, in place
     float2 *ws;         // queues x ring x 2^20
     const float2 *tw_1024;
     unsigned *sync;
     uint32_t count, ring, lag, queues;
-    uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence (timing experiments; results then invalid)
+    uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence, 4 = queue = XCD id
     uint32_t sleep;     // s_sleep argument of the polls is fixed; this many extra sleeps per poll iteration
     float scale;
     unsigned long long spin_limit; // wall_clock64 ticks (100 MHz) a poll may take before it gives up
@@ -371,9 +428,14 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
     float *plane = reinterpret_cast<float *>(sdsp_fft1m_smem);
     float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft1m_smem + kPlaneBytes);
     float2 *qtab = w1k + 1024;
-    unsigned *mail = reinterpret_cast<unsigned *>(qtab + 32 * kTile); // [0] this item's ticket, [1] go / abort
+    // mailbox: [0], [1] the item's ticket, alternating per iteration -- an iteration without work has no barrier between
+    // the other waves' read of its ticket and lane 0's write of the next one, so the next one goes to the other word;
+    // [2] go / abort of the item's wait
+    unsigned *mail = reinterpret_cast<unsigned *>(qtab + 32 * kTile);
 
-    const uint32_t q = blockIdx.x % a.queues;
+    // flags & 4 (lab): bind the workgroup to the queue of the XCD it runs on (HW_REG_XCC_ID, bits 3:0) -- a transform's two
+    // passes then run on ONE XCD and its intermediate is produced and consumed behind one L2
+    const uint32_t q = (a.flags & 4u) ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % a.queues : blockIdx.x % a.queues;
     if (q >= a.count)
         return;
     const uint32_t n_q = (a.count - q + a.queues - 1) / a.queues; // transforms of this queue
@@ -386,12 +448,12 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
     if (threadIdx.x == 0)
         next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    for (;;) {
+    for (unsigned it = 0;; it++) {
         // ---- this item's ticket (drawn one item ahead, so the atomic's latency hides behind the previous tile)
         if (threadIdx.x == 0)
-            mail[0] = next;
+            mail[it & 1] = next;
         __syncthreads(); // also: every wave has finished the previous item (plane / qtab are free)
-        const unsigned ticket = mail[0];
+        const unsigned ticket = mail[it & 1];
         if (ticket >= n_tickets)
             break;
         if (threadIdx.x == 0)
@@ -419,10 +481,10 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                mail[1] = ok ? 1u : 0u;
+                mail[2] = ok ? 1u : 0u;
             }
             __syncthreads();
-            if (mail[1] == 0u)
+            if (mail[2] == 0u)
                 break; // aborted: drain (uniform)
         }
 
@@ -437,7 +499,8 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
             __syncthreads();
             if (threadIdx.x == 0) {
-                if (!(a.flags & 1u)) {
+                // write-through (sc1) stores are at the fabric once drained: only plain stores need the L2 written back
+                if (!(LAYOUT & WS_SC1_STORES) && !(a.flags & 1u)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }

@@ -121,7 +121,6 @@ struct fft1m_fused_args {
     uint64_t count;
     uint32_t ring, lag;  // intermediate ring slots per queue; steps pass 2 trails pass 1 (lag < ring)
     uint32_t queues;     // independent ticket queues (workspace holds queues x ring transforms)
-    int layout;          // 0 rows, 1 blocked (fft1m_kernels.h: ws_layout)
     float scale;
     int reverse;
 };

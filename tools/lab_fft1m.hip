@@ -40,6 +40,24 @@ __global__ void fill_kernel(float2 *p, size_t n, uint32_t seed)
     }
 }
 
+// per transform: number of mismatching elements and the first mismatching index
+__global__ void compare_kernel(const uint2 *a, const uint2 *b, unsigned *bad, unsigned *first)
+{
+    const size_t base = (size_t)blockIdx.x << 20;
+    unsigned n = 0, f = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < (1u << 20); i += blockDim.x) {
+        const uint2 x = a[base + i], y = b[base + i];
+        if (x.x != y.x || x.y != y.y) {
+            n++;
+            f = f < i ? f : i;
+        }
+    }
+    if (n) {
+        atomicAdd(bad + blockIdx.x, n);
+        atomicMin(first + blockIdx.x, f);
+    }
+}
+
 template <typename K> static void set_lds(K kern)
 {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
@@ -208,73 +226,107 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(g_tw, tw.data(), 1024 * 8, hipMemcpyHostToDevice));
 
-    // ---- correctness of the persistent and the pipelined schedules: bit-identical to the two-launch schedule, several
-    // shapes, repeated (a lost or early hand-off shows as a mismatch)
+    // ---- exhaustive checks of the persistent schedule: every element of every transform against the two-launch
+    // schedule, launches back to back (warm caches, the ring re-used at once), batch sizes that leave queues uneven
     int bad_total = 0;
-    std::vector<float2> ha(1 << 20), hb(1 << 20);
-    auto compare = [&](const char *what) {
+    unsigned *d_bad, *d_first;
+    CK(hipMalloc(&d_bad, g_batch * 4));
+    CK(hipMalloc(&d_first, g_batch * 4));
+    std::vector<unsigned> h_bad(g_batch), h_first(g_batch);
+    auto check_all = [&](const char *what, uint32_t batch) {
+        CK(hipMemset(d_bad, 0, batch * 4));
+        CK(hipMemset(d_first, 0xff, batch * 4));
+        hipLaunchKernelGGL(compare_kernel, dim3(batch), dim3(1024), 0, 0, reinterpret_cast<const uint2 *>(g_data),
+                           reinterpret_cast<const uint2 *>(g_ref), d_bad, d_first);
+        CK(hipMemcpy(h_bad.data(), d_bad, batch * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h_first.data(), d_first, batch * 4, hipMemcpyDeviceToHost));
         const unsigned ab = read_abort();
-        size_t bad = 0;
-        int first_bad = -1, n_bad_x = 0;
-        for (uint32_t x = 0; x < g_batch; x += (g_batch > 32 ? g_batch / 32 : 1)) {
-            CK(hipMemcpy(ha.data(), g_data + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hb.data(), g_ref + ((size_t)x << 20), 8u << 20, hipMemcpyDeviceToHost));
-            size_t here = 0;
-            for (size_t i = 0; i < ha.size(); i++)
-                here += (ha[i].x != hb[i].x) || (ha[i].y != hb[i].y);
-            if (here) {
-                n_bad_x++;
-                if (first_bad < 0)
-                    first_bad = (int)x;
+        unsigned n_x = 0;
+        size_t total = 0;
+        for (uint32_t x = 0; x < batch; x++)
+            if (h_bad[x]) {
+                if (n_x < 6)
+                    std::printf("      transform %u: %u elements differ, first at %u (row %u col %u)\n", x, h_bad[x], h_first[x],
+                                h_first[x] >> 10, h_first[x] & 1023);
+                n_x++;
+                total += h_bad[x];
             }
-            bad += here;
-        }
-        std::printf("check %-48s %zu mismatching elements in %d transforms (first: %d)%s\n", what, bad, n_bad_x, first_bad,
-                    ab ? "  ABORTED" : "");
+        std::printf("check %-64s %zu elements in %u of %u transforms%s\n", what, total, n_x, batch, ab ? "  ABORTED" : "");
         std::fflush(stdout);
-        bad_total += bad != 0 || ab;
+        bad_total += n_x != 0 || ab;
     };
-    for (int rep = 0; rep < 2; rep++) {
-        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_ref, n, 1234u + rep);
-        two_launch<false, MODE_FFT, WS_ROWS>(g_ref, g_batch, 32);
-        CK(hipDeviceSynchronize());
-        const shape shapes[] = { { 1, 32, 24, 2 }, { 1, 1, 0, 2 }, { 1, 2, 1, 2 }, { 1, 8, 4, 2 }, { 1, 32, 24, 2 },
-                                 { 8, 2, 1, 2 },   { 8, 3, 1, 2 }, { 16, 2, 1, 2 }, { 4, 8, 4, 2 }, { 8, 4, 3, 3 } };
-        char what[160];
-        for (auto &sh : shapes)
-            for (int layout = 1; layout >= 0; layout--) {
-                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 1234u + rep);
-                if (layout)
-                    fused<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
-                else
-                    fused<false, MODE_FFT, WS_ROWS>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
+    struct cfg {
+        uint32_t queues, ring, lag, flags;
+        int layout;
+        const char *name;
+    };
+    const cfg cfgs[] = {
+        { 8, 3, 1, 0, WS_BLOCKED, "q8 r3 l1 plain stores + release, acquire + plain loads" },
+        { 8, 3, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r3 l1 sc1 stores (no release), acquire + plain loads" },
+        { 8, 3, 1, 1, WS_BLOCKED | WS_SC1_STORES | WS_STORE16, "q8 r3 l1 16-byte sc1 stores, acquire + plain loads" },
+        { 8, 4, 2, 1, WS_BLOCKED | WS_SC1_STORES | WS_STORE16, "q8 r4 l2 16-byte sc1 stores, acquire + plain loads" },
+        { 8, 2, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r2 l1 sc1 stores (no release), acquire + plain loads" },
+        { 8, 4, 2, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r4 l2 sc1 stores (no release), acquire + plain loads" },
+        { 16, 2, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q16 r2 l1 sc1 stores (no release), acquire + plain loads" },
+        { 4, 4, 2, 1, WS_BLOCKED | WS_SC1_STORES, "q4 r4 l2 sc1 stores (no release), acquire + plain loads" },
+        { 3, 3, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q3 r3 l1 (queues across XCDs) sc1 stores, acquire + plain loads" },
+        { 1, 1, 0, 1, WS_BLOCKED | WS_SC1_STORES, "q1 r1 l0 (slot re-used at once) sc1 stores, acquire + plain loads" },
+        { 1, 2, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q1 r2 l1 sc1 stores, acquire + plain loads" },
+        { 1, 8, 4, 1, WS_BLOCKED | WS_SC1_STORES, "q1 r8 l4 sc1 stores, acquire + plain loads" },
+        { 1, 32, 24, 0, WS_BLOCKED, "q1 r32 l24 plain stores + release, acquire + plain loads" },
+        { 1, 2, 1, 0, WS_BLOCKED, "q1 r2 l1 plain stores + release, acquire + plain loads" },
+    };
+    auto run_cfg = [&](const cfg &c, bool rev, uint32_t batch) {
+        g_flags = c.flags;
+#define RUN_L(L)                                                              \
+    if (rev)                                                                  \
+        fused<true, MODE_FFT, L>(g_data, batch, c.ring, c.lag, 2, c.queues);  \
+    else                                                                      \
+        fused<false, MODE_FFT, L>(g_data, batch, c.ring, c.lag, 2, c.queues)
+        switch (c.layout) {
+        case WS_BLOCKED: RUN_L(WS_BLOCKED); break;
+        case WS_BLOCKED | WS_SC1_STORES | WS_STORE16: RUN_L(WS_BLOCKED | WS_SC1_STORES | WS_STORE16); break;
+        default: RUN_L(WS_BLOCKED | WS_SC1_STORES); break;
+        }
+        g_flags = 0;
+    };
+    for (uint32_t batch : { 37u, g_batch }) {
+        const size_t nb = (size_t)batch << 20;
+        for (auto &c : cfgs) {
+            char what[200];
+            for (int rep = 0; rep < 2; rep++) {
+                // reference: forward, reverse, forward through the two-launch schedule
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_ref, nb, 500u + rep);
+                two_launch<false, MODE_FFT, WS_ROWS>(g_ref, batch, 32);
+                two_launch<true, MODE_FFT, WS_ROWS>(g_ref, batch, 32);
+                two_launch<false, MODE_FFT, WS_ROWS>(g_ref, batch, 32);
+                // the same three transforms back to back through the persistent schedule
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, nb, 500u + rep);
+                run_cfg(c, false, batch);
+                run_cfg(c, true, batch);
+                run_cfg(c, false, batch);
                 CK(hipDeviceSynchronize());
-                std::snprintf(what, sizeof what, "rep %d persistent q %u ring %u lag %u wg/CU %u layout %d:", rep, sh.queues, sh.ring,
-                              sh.lag, sh.per_cu, layout);
-                compare(what);
+                std::snprintf(what, sizeof what, "batch %u rep %d %s:", batch, rep, c.name);
+                check_all(what, batch);
             }
-        for (uint32_t chunk : { 4u, 8u, 16u })
-            for (int layout = 1; layout >= 0; layout--) {
-                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 1234u + rep);
-                if (layout)
-                    mixed<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, chunk);
-                else
-                    mixed<false, MODE_FFT, WS_ROWS>(g_data, g_batch, chunk);
-                CK(hipDeviceSynchronize());
-                g_last_queues = 1;
-                CK(hipMemset(g_sync, 0, 256));
-                std::snprintf(what, sizeof what, "rep %d pipelined launches chunk %u layout %d:", rep, chunk, layout);
-                compare(what);
-            }
+        }
     }
     std::printf("correctness: %s\n", bad_total ? "FAILED" : "ok");
     std::fflush(stdout);
-
+    // ---- timings
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 99u);
-    sweep<MODE_FFT, WS_BLOCKED>("fft ", "blocked", false);
-    sweep<MODE_FFT, WS_ROWS>("fft ", "rows   ", true);
-    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 99u);
-    sweep<MODE_MOVE, WS_BLOCKED>("move", "blocked", false);
-    sweep<MODE_HBM_ONLY, WS_BLOCKED>("hbm-only", "", false);
+    report("fft blocked two launches per chunk of 32", time_it([&](bool rev) {
+               if (rev)
+                   two_launch<true, MODE_FFT, WS_BLOCKED>(g_data, g_batch, 32);
+               else
+                   two_launch<false, MODE_FFT, WS_BLOCKED>(g_data, g_batch, 32);
+           }));
+    for (auto &c : cfgs) {
+        char what[200];
+        std::snprintf(what, sizeof what, "fft persistent q %u ring %u lag %u: %s", c.queues, c.ring, c.lag, c.name);
+        report(what, time_it([&](bool rev) { run_cfg(c, rev, g_batch); }));
+        if (read_abort())
+            std::printf("   ^^^ ABORTED\n");
+    }
     return bad_total ? 1 : 0;
 }
