@@ -49,35 +49,15 @@ constexpr size_t kLdsBytes = kPlaneBytes + 1024 * sizeof(float2) + 32 * kTile * 
 // whole 8 KiB rows).  BLOCKED: [n2 / 16][k1][n2 % 16] -- a pass-1 tile's output is ONE contiguous 128 KiB block,
 // pass 2 gathers 2 KiB pieces (16 rows x 128 B) from each of the 64 blocks.
 enum ws_layout { WS_ROWS = 0, WS_BLOCKED = 1 };
-// lab only, OR-ed into LAYOUT: the intermediate is stored write-through (sc1: straight to the fabric, the line is not kept in
-// the XCD's L2) / loaded with sc1 (bypasses the CU's L1) -- the hand-off forms of cdna_hip_programming.md Guideline 16 that
-// need no release fence
-enum ws_access { WS_SC1_STORES = 2, WS_SC1_LOADS = 4, WS_STORE16 = 8 };
-// 16-byte write-through store: base (uniform) + 32-bit byte offset
-__device__ __forceinline__ void ws_store16_sc1(float2 *base, uint32_t byte_off, float2 lo, float2 hi)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f v = { lo.x, lo.y, hi.x, hi.y };
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
-}
-// the value the neighbouring lane (lane ^ 1) holds
-__device__ __forceinline__ float swap_lane1(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
-}
+// OR-ed into LAYOUT: the intermediate is stored write-through (sc1: straight to the fabric, the line is not kept in the
+// XCD's L2) -- the hand-off form of cdna_hip_programming.md Guideline 16 (R1) that needs no release fence.  (16-byte
+// write-through stores, two columns per lane after a DPP lane swap, measured no faster: 40.9 / 41.7 % against 41.4 / 42.2 %.)
+enum ws_access { WS_SC1_STORES = 2 };
 __device__ __forceinline__ void ws_store_sc1(float2 *p, float2 v)
 {
     unsigned long long bits;
     __builtin_memcpy(&bits, &v, 8);
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ws_load_sc1(const float2 *p)
-{
-    const unsigned long long bits =
-        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float2 v;
-    __builtin_memcpy(&v, &bits, 8);
-    return v;
 }
 // What a tile does.  MODE_FFT is the product.  The other two exist for tools/lab_fft1m.hip only: the same loads and
 // stores without the butterflies (MODE_MOVE), and without the intermediate's traffic either (MODE_HBM_ONLY: what the
@@ -164,28 +144,6 @@ __device__ __forceinline__ void cols_tile(const float2 *in_x, float2 *ws_x, uint
         soff = (bu * 1024 + c) * 8u;
     }
     constexpr int kStep = (LAYOUT & 1) == WS_BLOCKED ? 32 * 16 : 32 * 1024; // float2 elements between k1 and k1 + 32
-    if constexpr ((LAYOUT & WS_STORE16) != 0) {
-        // 16-byte stores: registers 2m and 2m+1 (rows k1 and k1 + 512 of the same column) of an even / odd lane pair are
-        // regrouped so that the even lane holds row k1 of columns (c, c+1) and the odd lane row k1 + 512 of (c-1, c)
-        static_assert((LAYOUT & 1) == WS_BLOCKED && (LAYOUT & WS_SC1_STORES), "16-byte stores: blocked layout, write-through");
-        const bool odd = (c & 1) != 0;
-        const uint32_t soff16 = (bu * 16 + (c & ~1u)) * 8u + (odd ? 16u * kStep * 8u : 0u); // brev5(2m+1) = brev5(2m) + 16
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            if ((m & 3) == 0)
-                __builtin_amdgcn_sched_barrier(0);
-            float2 a = x[2 * m], b = x[2 * m + 1];
-            if constexpr (MATH) {
-                a = cmul(a, cmul(pw, qcol[16 * (int)(__brev((uint32_t)(2 * m)) >> 27)]));
-                b = cmul(b, cmul(pw, qcol[16 * (int)(__brev((uint32_t)(2 * m + 1)) >> 27)]));
-            }
-            const float2 send = odd ? a : b;
-            const float2 recv = float2{ swap_lane1(send.x), swap_lane1(send.y) };
-            const float2 lo = odd ? recv : a, hi = odd ? b : recv;
-            ws_store16_sc1(dst_tile + kStep * (int)(__brev((uint32_t)(2 * m)) >> 27), soff16, lo, hi);
-        }
-        return;
-    }
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0) // keep at most 8 elements' table reads in flight (register budget)
@@ -224,13 +182,13 @@ __device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uin
         const uint32_t aoff = ((ua >> 4) * (1024 * kTile) + ra * 16 + (ua & 15)) * 8u;
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            x[k] = (LAYOUT & WS_SC1_LOADS) ? ws_load_sc1(at(src + 2 * k * (1024 * kTile), aoff)) : *at(src + 2 * k * (1024 * kTile), aoff);
+            x[k] = *at(src + 2 * k * (1024 * kTile), aoff);
     } else {
         const float2 *src = ws_x + (size_t)tile * kTile * 1024;
         const uint32_t aoff = (ra * 1024 + ua) * 8u; // bytes
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            x[k] = (LAYOUT & WS_SC1_LOADS) ? ws_load_sc1(at(src + 32 * k, aoff)) : *at(src + 32 * k, aoff);
+            x[k] = *at(src + 32 * k, aoff);
     }
     // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
     const uint32_t rb = t & 15, ub = t >> 4;

@@ -140,7 +140,8 @@ def test_more_than_eight_sections(sd, torch_cuda, oracle, m):
     b32 = _bank(sd, m, 70, sd.F32, sd.IIR_GENERIC, 1, 10e3, 100e3, 0.0)
     fo = oracle.iir(m)
     fo.set_lp_coeff(10e3, 100e3)
-    assert rel_max_err(_process(torch_cuda, b32, x.astype(np.float32))[7], fo.process(x[7].astype(np.float32).astype(np.float64))) < 3e-6
+    # f32: every cascaded section adds its rounding noise -- the 1e-6 of the four-section BASELINE filter scaled by m / 4, x2
+    assert rel_max_err(_process(torch_cuda, b32, x.astype(np.float32))[7], fo.process(x[7].astype(np.float32).astype(np.float64))) < 2e-6 * m / 4
     with pytest.raises(sd.SdspHipError):
         _process(torch_cuda, _bank(sd, 18, 2, sd.F64, sd.IIR_GENERIC, 1, 3e3, 48e3, 0.0), x[:2])
 

@@ -263,8 +263,6 @@ int main(int argc, char **argv)
     const cfg cfgs[] = {
         { 8, 3, 1, 0, WS_BLOCKED, "q8 r3 l1 plain stores + release, acquire + plain loads" },
         { 8, 3, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r3 l1 sc1 stores (no release), acquire + plain loads" },
-        { 8, 3, 1, 1, WS_BLOCKED | WS_SC1_STORES | WS_STORE16, "q8 r3 l1 16-byte sc1 stores, acquire + plain loads" },
-        { 8, 4, 2, 1, WS_BLOCKED | WS_SC1_STORES | WS_STORE16, "q8 r4 l2 16-byte sc1 stores, acquire + plain loads" },
         { 8, 2, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r2 l1 sc1 stores (no release), acquire + plain loads" },
         { 8, 4, 2, 1, WS_BLOCKED | WS_SC1_STORES, "q8 r4 l2 sc1 stores (no release), acquire + plain loads" },
         { 16, 2, 1, 1, WS_BLOCKED | WS_SC1_STORES, "q16 r2 l1 sc1 stores (no release), acquire + plain loads" },
@@ -285,7 +283,6 @@ int main(int argc, char **argv)
         fused<false, MODE_FFT, L>(g_data, batch, c.ring, c.lag, 2, c.queues)
         switch (c.layout) {
         case WS_BLOCKED: RUN_L(WS_BLOCKED); break;
-        case WS_BLOCKED | WS_SC1_STORES | WS_STORE16: RUN_L(WS_BLOCKED | WS_SC1_STORES | WS_STORE16); break;
         default: RUN_L(WS_BLOCKED | WS_SC1_STORES); break;
         }
         g_flags = 0;
