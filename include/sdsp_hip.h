@@ -38,7 +38,15 @@ typedef enum {
     SDSP_HIP_ERR_NOMEM = -6
 } sdsp_hip_status;
 
-typedef enum { SDSP_HIP_F32 = 0, SDSP_HIP_F64 = 1 } sdsp_hip_precision;
+typedef enum {
+    SDSP_HIP_F32 = 0,
+    SDSP_HIP_F64 = 1,
+    /* IIR banks only: samples stored as float (8 bytes of HBM traffic per sample, like F32), per-channel state,
+     * coefficients and the recurrence in double -- the reference computes in double (casc_2o_iir.h:11-18), and an f32
+     * recurrence loses up to 1e-4 at low normalised cutoffs (f0/fs = 0.005); this mode is within float rounding of the
+     * double result everywhere.  State buffers then hold doubles. */
+    SDSP_HIP_F32_F64STATE = 2
+} sdsp_hip_precision;
 /* forward_fft / reverse_fft policy, fft.h:121-146 (reverse: conjugate twiddles and 1/N scale) */
 typedef enum { SDSP_HIP_FORWARD = 1, SDSP_HIP_REVERSE = -1 } sdsp_hip_direction;
 /* filter_type.h:6 -- the same integer values */

@@ -4,7 +4,7 @@ The product is the HIP library (csrc/ -> lib/libsdsp_hip.so) behind the C ABI in
 this package is its Python host mirror.  Importing does not touch the GPU; any compute call without
 the library or without a HIP device raises (there is no CPU path here).
 """
-from ._lib import (F32, F64, FORWARD, REVERSE, IIR_GENERIC, IIR_LP, IIR_HP, IIR_BP, FILTER_NONE,
+from ._lib import (F32, F64, F32_F64STATE, FORWARD, REVERSE, IIR_GENERIC, IIR_LP, IIR_HP, IIR_BP, FILTER_NONE,
                    FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS, FILTER_BAND_STOP, SdspHipError, load)
 from .fft import (FftPlan, RfftPlan, fft_radix2, fft_radix4, forward_fft, reverse_fft, log2, log4, isPowerOf2,
                   isPowerOf4, digit_reverse, calc_swap_lookup, calc_twiddles, calc_wCoeffs)

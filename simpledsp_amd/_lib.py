@@ -12,6 +12,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "lib" / "libsdsp_hip.so"
 
 F32, F64 = 0, 1
+F32_F64STATE = 2  # IIR banks: float samples, double state / recurrence
 FORWARD, REVERSE = 1, -1
 FILTER_NONE, FILTER_LOW_PASS, FILTER_HIGH_PASS, FILTER_BAND_PASS = 0, 1, 2, 3
 FILTER_BAND_STOP = 4

@@ -154,6 +154,29 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
 
 constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
+// Tables of fft_mix.hip (N = R x 4096, R = 2 / 4): the N = 4096 radix-4 thread-twiddle table built from W_4096^j = W_N^(R j),
+// and the leading stage's thread twiddles [q - 1][t] = W_N^(q t), q < R, t < 256.
+int upload_thread_twiddles_mix(const std::vector<double> &w, uint32_t n, void **sub, void **lead)
+{
+    const uint32_t R = n / 4096;
+    std::vector<double> w4096(2 * 4096);
+    for (uint32_t j = 0; j < 4096; j++) {
+        w4096[2 * j] = w[2 * (size_t)(R * j)];
+        w4096[2 * j + 1] = w[2 * (size_t)(R * j) + 1];
+    }
+    if (int rc = upload_thread_twiddles_4096(w4096, 4, sub))
+        return rc;
+    std::vector<float> tab;
+    for (uint32_t q = 1; q < R; q++)
+        for (uint32_t t = 0; t < 256; t++) {
+            tab.push_back((float)w[2 * (size_t)(q * t)]);
+            tab.push_back((float)w[2 * (size_t)(q * t) + 1]);
+        }
+    HIP_TRY(hipMalloc(lead, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*lead, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
 enum fft_path { PATH_NOOP = 0, PATH_TILE = 1, PATH_FFT4096 = 2, PATH_FOUR_STEP = 3, PATH_FFT1M = 4, PATH_REG = 5 };
 } // namespace
 
@@ -169,6 +192,8 @@ struct sdsp_hip_fft_plan {
     void *twt = nullptr;           // tuned N = 4096 f32 kernels: thread-twiddle table
     void *twt_reg = nullptr;       // register-pass family (f32): thread-twiddle table
     void *twt_big = nullptr;       // fft_big.hip: thread-twiddle table
+    void *twt_mix = nullptr;       // fft_mix.hip (N = 8192 / 16384): the sub-transforms' thread-twiddle table ...
+    void *tw_lead = nullptr;       // ... and the leading stage's thread twiddles W_N^(q t)
     uint32_t n1 = 0, n2 = 0;       // four-step split
     uint32_t cols = 1, pitch = 1;  // tile shape (single pass)
     uint32_t cols1 = 1, pitch1 = 1, cols2 = 1, pitch2 = 1;
@@ -184,6 +209,7 @@ struct sdsp_hip_fft_plan {
     sdsp_hip_fft_plan *mid_rows = nullptr; // N = 2^16 .. 2^19 f32: plan of the 16 row transforms (fft_mid.hip)
     void *tw1024 = nullptr;                // ... and W_1024^j, the coarse factor of its inter-pass twiddle
     int real_mode = 0;                    // 0 complex; 1 real forward; 2 real inverse (n = n_real / 2)
+    bool allow_mix = false;               // radix-4 stages behind one leading radix-2 / radix-4 stage may serve this plan
 };
 
 struct sdsp_hip_iir_plan {
@@ -253,8 +279,23 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft4096_r2_f32(a, stream);
     }
 
-    // N = 8192 / 16384 / 32768 radix 2 f32: registers-resident single-pass kernel (fft_big.hip)
-    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == 0 &&
+    // N = 8192 / 16384 f32, either stage type: one leading radix-2 / radix-4 stage + the tuned N = 4096 radix-4 machinery
+    const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
+    if (mix_size && variant == 0) {
+        fft_mix_args a;
+        a.data = data;
+        a.tw = p->twt_mix;
+        a.tw_lead = p->tw_lead;
+        a.n = p->n;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = rev;
+        return launch_fft_mix_f32(a, stream);
+    }
+
+    // N = 32768 (variant 0) and N = 8192 / 16384 (variant 1), f32: radix-2 stages, registers-resident single-pass kernel
+    // (fft_big.hip)
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == (mix_size ? 1 : 0) &&
         !p->real_mode && fft_big_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
@@ -291,7 +332,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.batch = batch;
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
-        a.nontemporal = variant != 1; // 0 (and 2 at n = 4096 radix 2, where 0 is the tuned kernel)
+        a.nontemporal = variant != 1 || mix_size; // 1: default cache policy (N < 8192)
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
         return launch_fft_reg_f32(a, stream);
@@ -521,7 +562,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     *out = nullptr;
     // radix 0 (SDSP_HIP_RADIX_AUTO): radix-4 stages where n is a power of 4, radix-2 stages otherwise -- the
     // "mixed" entry of SURVEY 8(f)-4: any power of two without the caller choosing the function
-    if (radix == SDSP_HIP_RADIX_AUTO) {
+    const bool radix_auto = radix == SDSP_HIP_RADIX_AUTO;
+    if (radix_auto) {
         if (!sdsp_hip_is_power_of_2(n))
             return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
         radix = sdsp_hip_is_power_of_4(n) ? 4 : 2;
@@ -552,6 +594,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     p->precision = precision;
     p->device = device;
     p->max_batch = max_batch ? max_batch : 1;
+    // An explicit radix is the stage type that runs (radix 2: radix-2 butterflies only; radix 4: radix-4 only).  AUTO asks
+    // for the fastest kernel: at N = 2 * 4^k that is the radix-4 machinery behind ONE radix-2 stage.
+    p->allow_mix = radix_auto || radix == 4;
 
     int rc = SDSP_HIP_OK;
     std::vector<double> w;
@@ -577,6 +622,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
             rc = upload_thread_twiddles_big(w, n, &p->twt_big);
+        if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
+            rc = upload_thread_twiddles_mix(w, n, &p->twt_mix, &p->tw_lead);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
         if (p->cols > 16)
             pick_tile(precision, n, 16, &p->cols, &p->pitch);
@@ -681,6 +728,8 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->twt);
         (void)hipFree(p->twt_reg);
         (void)hipFree(p->twt_big);
+        (void)hipFree(p->twt_mix);
+        (void)hipFree(p->tw_lead);
         (void)hipFree(p->tw1024);
         (void)hipFree(p->workspace);
         (void)hipFree(p->host_stage);
@@ -830,8 +879,9 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->direction = p->direction;
     info->precision = p->precision;
     info->device = p->device;
-    const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 &&
-                     !p->real_mode && fft_big_supports(p->n, p->radix);
+    const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
+    const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 &&
+                     p->variant == (mix_size ? 1 : 0) && !p->real_mode && fft_big_supports(p->n, p->radix);
     const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0;
     info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
     if (mid) { // column step + the rows' own passes + untwist
@@ -852,6 +902,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
     if (big)
         name = "sdsp_fft_big_kernel";
+    if (mix_size && p->variant == 0)
+        name = "sdsp_fft_mix_f32";
     if (mid)
         name = "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
@@ -894,8 +946,8 @@ int sdsp_hip_iir_plan_create(sdsp_hip_iir_plan **out, uint32_t sections, int kin
         return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
     if (!a || (kind == SDSP_HIP_IIR_GENERIC && !b))
         return fail(SDSP_HIP_ERR_INVALID_ARG, "coefficient pointer is null");
-    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64)
-        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32 or SDSP_HIP_F64");
+    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64 && precision != SDSP_HIP_F32_F64STATE)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32, SDSP_HIP_F64 or SDSP_HIP_F32_F64STATE");
     if (int rc = use_device(device))
         return rc;
     auto *p = new sdsp_hip_iir_plan();
@@ -921,7 +973,7 @@ int sdsp_hip_iir_state_bytes(const sdsp_hip_iir_plan *p, uint64_t channels, uint
 {
     if (!p || !bytes)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
-    *bytes = 3ull * (p->sections + 1) * channels * (p->precision == SDSP_HIP_F64 ? 8 : 4);
+    *bytes = 3ull * (p->sections + 1) * channels * (p->precision == SDSP_HIP_F32 ? 4 : 8);
     return SDSP_HIP_OK;
 }
 
@@ -1006,7 +1058,7 @@ int sdsp_hip_iir_process_host(sdsp_hip_iir_plan *p, void *host_data, uint64_t ch
         return fail(SDSP_HIP_ERR_INVALID_ARG, "data is null");
     if (int rc = use_device(p->device))
         return rc;
-    const size_t rs = p->precision == SDSP_HIP_F64 ? 8 : 4;
+    const size_t rs = p->precision == SDSP_HIP_F64 ? 8 : 4; // sample size (the mixed mode stores floats)
     const size_t data_bytes = ((channels - 1) * stride + samples) * rs;
     uint64_t state_bytes = 0;
     sdsp_hip_iir_state_bytes(p, channels, &state_bytes);

@@ -51,7 +51,7 @@ int launch_fft4096_conv_f32(void *data, const void *tw, const void *h, uint64_t 
     if (batch > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sdsp_fft4096_conv_f32, dim3((uint32_t)batch), dim3(256), 0, s, reinterpret_cast<float2 *>(data),
+    hipLaunchKernelGGL(sdsp_fft4096_conv_f32<true>, dim3((uint32_t)batch), dim3(256), 0, s, reinterpret_cast<float2 *>(data),
                        reinterpret_cast<const float2 *>(tw), reinterpret_cast<const float2 *>(h), batch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -295,18 +295,19 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
 // same LDS tile.  HBM sees one read and one write per element instead of three of each.
 
 // all six stages on one transform held as x[k] = element t + 256 k; returns with
-// x[k] = result[t + 256 * (4 (k & 3) + (k >> 2))].  w*: FORWARD twiddles, conjugated here when REV.
-template <bool REV>
+// x[k] = result[t + 256 * (4 (k & 3) + (k >> 2))].  w*: the twiddles; conjugated here when CONJ (the fused convolution
+// runs its reverse half from the FORWARD plan's table; fft_mix.hip passes tables already folded for the direction).
+template <bool REV, bool CONJ = REV>
 __device__ __forceinline__ void fft4096_in_regs(float2 (&x)[16], float2 *lds, const lds_map &mp, const float2 (&wA1)[3],
                                                 const float2 (&wA2)[3], const float2 (&wB1)[3], const float2 (&wB2)[3])
 {
     float2 a1[3], a2[3], b1[3], b2[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        a1[r] = float2{ wA1[r].x, REV ? -wA1[r].y : wA1[r].y };
-        a2[r] = float2{ wA2[r].x, REV ? -wA2[r].y : wA2[r].y };
-        b1[r] = float2{ wB1[r].x, REV ? -wB1[r].y : wB1[r].y };
-        b2[r] = float2{ wB2[r].x, REV ? -wB2[r].y : wB2[r].y };
+        a1[r] = float2{ wA1[r].x, CONJ ? -wA1[r].y : wA1[r].y };
+        a2[r] = float2{ wA2[r].x, CONJ ? -wA2[r].y : wA2[r].y };
+        b1[r] = float2{ wB1[r].x, CONJ ? -wB1[r].y : wB1[r].y };
+        b2[r] = float2{ wB2[r].x, CONJ ? -wB2[r].y : wB2[r].y };
     }
     two_stages<REV, true, true>(x, a1, a2);
     lds_write_a(lds, mp, x);
@@ -320,6 +321,7 @@ __device__ __forceinline__ void fft4096_in_regs(float2 (&x)[16], float2 *lds, co
     two_stages<REV, false, false>(x, a1, a2);
 }
 
+template <bool REVERSE_HALF = true> // (a template so that only the translation unit that launches it instantiates it)
 __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                const float2 *__restrict__ h, uint64_t batch)
 {
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restri
             const int j = 4 * (k & 3) + (k >> 2);
             z[j] = cmul(x[k], h[t + 256 * j]);
         }
-        fft4096_in_regs<true>(z, lds, mp, wA1, wA2, wB1, wB2);
+        fft4096_in_regs<REVERSE_HALF>(z, lds, mp, wA1, wA2, wB1, wB2);
         float2 *dst = data + f * 4096 + t;
 #pragma unroll
         for (int k = 0; k < 16; k++) {

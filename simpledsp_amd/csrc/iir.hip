@@ -24,13 +24,26 @@ namespace sdsp_hip
 {
 namespace
 {
-template <typename R, int M> struct iir_dev_args {
-    R *data;
+// S: the type the samples are stored in; R: the type the recurrence (state, coefficients, arithmetic) runs in.
+// (float, float), (double, double), or -- the mixed mode, SDSP_HIP_F32_F64STATE -- (float, double): 8 bytes of HBM traffic per
+// sample with the double-precision recurrence's accuracy (f32 state loses 1e-4 at f0/fs = 0.005).
+template <typename S, typename R, int M> struct iir_dev_args {
+    S *data;
     R *state; // nullable; state[(3*j + age) * channels + c]
     uint64_t channels, samples, stride;
     R gain;
     R a1[M], a2[M], b1[M], b2[M];
 };
+
+// a kernel's pair of types: S samples in memory, R recurrence
+template <typename S_, typename R_> struct prec {
+    using S = S_;
+    using R = R_;
+    static constexpr bool fused = sizeof(S_) == 4; // f32 and mixed: parity by tolerance; f64: bit-exact operation order
+};
+using prec_f32 = prec<float, float>;
+using prec_f64 = prec<double, double>;
+using prec_mix = prec<float, double>;
 
 template <typename R> struct vec16;
 template <> struct vec16<float> {
@@ -76,30 +89,34 @@ template <typename R, bool NT> __device__ __forceinline__ void gstore16(R *p, ty
 // One sample through the cascade.  y1[j] / y2[j] are level j's values one / two samples ago
 // (level 0 = gain-scaled input, level M = output): the reference's m_mem ring (casc_2o_iir.h:15)
 // with the ring index resolved at compile time.
-template <typename R, int KIND, int M>
-__device__ __forceinline__ R cascade_step(R x, const iir_dev_args<R, M> &p, R (&y1)[M + 1], R (&y2)[M + 1],
-                                          R (&y3)[M + 1])
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// FUSED: parity by tolerance (f32 and mixed mode) -- each "x*b - y*a" pair is a multiply and an FMA; !FUSED (f64): the
+// reference's exact operation order, bit for bit.
+template <typename R, int KIND, int M, bool FUSED, typename ARGS>
+__device__ __forceinline__ R cascade_step(R x, const ARGS &p, R (&y1)[M + 1], R (&y2)[M + 1], R (&y3)[M + 1])
 {
     R cur[M + 1];
     cur[0] = x * p.gain; // :52 / :242
 #pragma unroll
     for (int j = 0; j < M; j++) {
         R acc = cur[j];
-        if constexpr (sizeof(R) == 4) {
-            // f32 (parity by tolerance, 1e-6): same terms, grouped as the reference groups them, but
+        if constexpr (FUSED) {
+            // parity by tolerance (1e-6): same terms, grouped as the reference groups them, but
             // each "x*b - y*a" pair costs a multiply and an FMA instead of two multiplies and a subtract
             if constexpr (KIND == SDSP_HIP_IIR_GENERIC) {
-                acc += __builtin_fmaf(y1[j], p.b1[j], -(y1[j + 1] * p.a1[j]));
-                acc += __builtin_fmaf(y2[j], p.b2[j], -(y2[j + 1] * p.a2[j]));
+                acc += fma_t(y1[j], p.b1[j], -(y1[j + 1] * p.a1[j]));
+                acc += fma_t(y2[j], p.b2[j], -(y2[j + 1] * p.a2[j]));
             } else if constexpr (KIND == SDSP_HIP_IIR_LP) {
-                acc += __builtin_fmaf(-y1[j + 1], p.a1[j], y1[j] + y1[j]);
-                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], y2[j]);
+                acc += fma_t(-y1[j + 1], p.a1[j], y1[j] + y1[j]);
+                acc += fma_t(-y2[j + 1], p.a2[j], y2[j]);
             } else if constexpr (KIND == SDSP_HIP_IIR_HP) {
-                acc += __builtin_fmaf(-y1[j + 1], p.a1[j], -y1[j] - y1[j]);
-                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], y2[j]);
+                acc += fma_t(-y1[j + 1], p.a1[j], -y1[j] - y1[j]);
+                acc += fma_t(-y2[j + 1], p.a2[j], y2[j]);
             } else {
                 acc += -y1[j + 1] * p.a1[j];
-                acc += __builtin_fmaf(-y2[j + 1], p.a2[j], -y2[j]);
+                acc += fma_t(-y2[j + 1], p.a2[j], -y2[j]);
             }
         } else if constexpr (KIND == SDSP_HIP_IIR_GENERIC) { // :67-68
             acc += y1[j] * p.b1[j] - y1[j + 1] * p.a1[j];
@@ -125,8 +142,8 @@ __device__ __forceinline__ R cascade_step(R x, const iir_dev_args<R, M> &p, R (&
     return cur[M]; // :71 / :254
 }
 
-template <typename R, int M>
-__device__ __forceinline__ void load_state(const iir_dev_args<R, M> &p, uint64_t c, R (&y1)[M + 1],
+template <typename R, int M, typename ARGS>
+__device__ __forceinline__ void load_state(const ARGS &p, uint64_t c, R (&y1)[M + 1],
                                            R (&y2)[M + 1], R (&y3)[M + 1])
 {
 #pragma unroll
@@ -143,8 +160,8 @@ __device__ __forceinline__ void load_state(const iir_dev_args<R, M> &p, uint64_t
     }
 }
 
-template <typename R, int M>
-__device__ __forceinline__ void store_state(const iir_dev_args<R, M> &p, uint64_t c, const R (&y1)[M + 1],
+template <typename R, int M, typename ARGS>
+__device__ __forceinline__ void store_state(const ARGS &p, uint64_t c, const R (&y1)[M + 1],
                                             const R (&y2)[M + 1], const R (&y3)[M + 1])
 {
     if (p.state) {
@@ -158,28 +175,32 @@ __device__ __forceinline__ void store_state(const iir_dev_args<R, M> &p, uint64_
 }
 
 // ---- direct variant: lane = channel, scalar global accesses.  Any alignment, any length.
-template <typename R, int KIND, int M>
-__global__ __launch_bounds__(256) void sdsp_iir_direct_kernel(iir_dev_args<R, M> p)
+template <typename P, int KIND, int M>
+__global__ __launch_bounds__(256) void sdsp_iir_direct_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
+    using S = typename P::S;
+    using R = typename P::R;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.channels)
         return;
     R y1[M + 1], y2[M + 1], y3[M + 1];
     load_state<R, M>(p, c, y1, y2, y3);
-    R *row = p.data + c * p.stride;
+    S *row = p.data + c * p.stride;
     for (uint64_t s = 0; s < p.samples; s++)
-        row[s] = cascade_step<R, KIND, M>(row[s], p, y1, y2, y3);
+        row[s] = (S)cascade_step<R, KIND, M, P::fused>((R)row[s], p, y1, y2, y3);
     store_state<R, M>(p, c, y1, y2, y3);
 }
 
 // ---- tiled variant.  ROWB = bytes of one channel covered per tile (T = ROWB / sizeof(R) samples).
 // Requirements (checked by the host): data 16-byte aligned, stride and samples multiples of 16 B.
-template <typename R, int KIND, int M, int ROWB, bool NT>
-__global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> p)
+template <typename P, int KIND, int M, int ROWB, bool NT>
+__global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
-    using V = typename vec16<R>::type;
-    constexpr int EPV = vec16<R>::n;             // elements per 16-byte vector
-    constexpr int T = ROWB / (int)sizeof(R);      // samples per tile row
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = typename vec16<S>::type;
+    constexpr int EPV = vec16<S>::n;             // elements per 16-byte vector
+    constexpr int T = ROWB / (int)sizeof(S);      // samples per tile row
     constexpr int NV = ROWB / 16;                 // vectors per row == lanes per row
     constexpr int RPI = 64 / NV;                  // rows covered by one wave-wide access
     constexpr int PITCH = ROWB + 16;              // LDS row pitch in bytes (one vector of padding)
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
             const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
             stage[i] = V{};
             if (ch < p.channels && s0 < p.samples)
-                stage[i] = gload16<R, NT>(p.data + ch * p.stride + s0);
+                stage[i] = gload16<S, NT>(p.data + ch * p.stride + s0);
         }
     };
 
@@ -233,19 +254,19 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 V x = myrow[v];
-                R *xe = reinterpret_cast<R *>(&x);
+                S *xe = reinterpret_cast<S *>(&x);
 #pragma unroll
                 for (int e = 0; e < EPV; e++)
-                    xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
                 myrow[v] = x;
             }
         } else {
             for (int v = 0; v * EPV < valid; v++) { // samples is a multiple of EPV
                 V x = myrow[v];
-                R *xe = reinterpret_cast<R *>(&x);
+                S *xe = reinterpret_cast<S *>(&x);
 #pragma unroll
                 for (int e = 0; e < EPV; e++)
-                    xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
                 myrow[v] = x;
             }
         }
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
             const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
             if (ch < p.channels && s0 < p.samples) {
                 const V v = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
-                gstore16<R, NT>(p.data + ch * p.stride + s0, v);
+                gstore16<S, NT>(p.data + ch * p.stride + s0, v);
             }
         }
         __syncthreads();
@@ -275,13 +296,15 @@ __global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<R, M> 
 // The super-tile stays in registers (128 VGPRs); its four 128-byte sub-tiles go through a padded
 // 9 KiB LDS transpose one after the other, and the filtered samples return to the same registers,
 // so the stores have the same burst shape as the loads.
-template <typename R, int KIND, int M, bool NT, int SUBS>
-__global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, M> p)
+template <typename P, int KIND, int M, bool NT, int SUBS>
+__global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
-    using V = typename vec16<R>::type;
-    constexpr int EPV = vec16<R>::n;          // elements per 16-byte vector
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = typename vec16<S>::type;
+    constexpr int EPV = vec16<S>::n;          // elements per 16-byte vector
     constexpr int ROWB = 128;                 // bytes of one channel per sub-tile
-    constexpr int T = ROWB / (int)sizeof(R);  // samples per sub-tile
+    constexpr int T = ROWB / (int)sizeof(S);  // samples per sub-tile
     constexpr int NV = ROWB / 16;             // = 8 vectors per sub-row = lanes per row
     constexpr int RPI = 64 / NV;              // = 8 rows per wave-wide access
     // SUBS = sub-tiles per super-tile: 4 -> 512 B per channel per burst, 128 data VGPRs
@@ -302,18 +325,18 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
     // interior workgroups (all 64 channels exist) take an unguarded path for their full super-tiles:
     // one per-lane base pointer + wave-uniform offsets, no per-access predicates
     const bool interior = ch0 + 64 <= p.channels;
-    R *const lane_base = p.data + (ch0 + sub) * p.stride + (uint64_t)piece * EPV;
+    S *const lane_base = p.data + (ch0 + sub) * p.stride + (uint64_t)piece * EPV;
     const uint64_t group_step = (uint64_t)RPI * p.stride; // elements between row groups
     for (uint64_t st = 0; st < n_super; st++) {
         V stage[SUBS * NV]; // register SUBS*i + j: rows 8i..8i+7, sub-tile j
         const bool full = interior && (st + 1) * SUBS * T <= p.samples;
-        R *const tile_base = lane_base + st * SUBS * T;
+        S *const tile_base = lane_base + st * SUBS * T;
         if (full) {
 #pragma unroll
             for (int i = 0; i < NV; i++)
 #pragma unroll
                 for (int j = 0; j < SUBS; j++)
-                    stage[SUBS * i + j] = gload16<R, NT>(tile_base + i * group_step + j * T);
+                    stage[SUBS * i + j] = gload16<S, NT>(tile_base + i * group_step + j * T);
         } else {
 #pragma unroll
             for (int i = 0; i < NV; i++) {
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
                     const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
                     stage[SUBS * i + j] = V{};
                     if (ch < p.channels && s0 < p.samples)
-                        stage[SUBS * i + j] = gload16<R, NT>(p.data + ch * p.stride + s0);
+                        stage[SUBS * i + j] = gload16<S, NT>(p.data + ch * p.stride + s0);
                 }
             }
         }
@@ -343,19 +366,19 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     V x = myrow[v];
-                    R *xe = reinterpret_cast<R *>(&x);
+                    S *xe = reinterpret_cast<S *>(&x);
 #pragma unroll
                     for (int e = 0; e < EPV; e++)
-                        xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                        xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
                     myrow[v] = x;
                 }
             } else {
                 for (int v = 0; v * EPV < valid; v++) {
                     V x = myrow[v];
-                    R *xe = reinterpret_cast<R *>(&x);
+                    S *xe = reinterpret_cast<S *>(&x);
 #pragma unroll
                     for (int e = 0; e < EPV; e++)
-                        xe[e] = cascade_step<R, KIND, M>(xe[e], p, y1, y2, y3);
+                        xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
                     myrow[v] = x;
                 }
             }
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
             for (int i = 0; i < NV; i++)
 #pragma unroll
                 for (int j = 0; j < SUBS; j++)
-                    gstore16<R, NT>(tile_base + i * group_step + j * T, stage[SUBS * i + j]);
+                    gstore16<S, NT>(tile_base + i * group_step + j * T, stage[SUBS * i + j]);
         } else {
 #pragma unroll
             for (int i = 0; i < NV; i++) {
@@ -379,7 +402,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<R, 
                 for (int j = 0; j < SUBS; j++) {
                     const uint64_t s0 = (st * SUBS + j) * T + (uint64_t)piece * EPV;
                     if (ch < p.channels && s0 < p.samples)
-                        gstore16<R, NT>(p.data + ch * p.stride + s0, stage[SUBS * i + j]);
+                        gstore16<S, NT>(p.data + ch * p.stride + s0, stage[SUBS * i + j]);
                 }
             }
         }
@@ -429,10 +452,12 @@ template <typename R, int VEC, bool NT> __device__ __forceinline__ void gstore_c
 // U rows are being filtered while the next U are in flight (double buffer).  Measured with 16-byte lanes on the
 // BASELINE config-4 shape: U = 2: 51 %, 4: 63 %, 8: 66 % of HBM peak; a single ring of 8 / 16 row registers that
 // is refilled row by row (same rows in flight, half the registers): 62 % / 61 %.
-template <typename R, int KIND, int M, bool NT, int VEC, int U>
-__global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R, M> p)
+template <typename P, int KIND, int M, bool NT, int VEC, int U>
+__global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
-    using V = chan_vec<R, VEC>;
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = chan_vec<S, VEC>;
     const uint64_t c0 = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * VEC;
     if (c0 >= p.channels)
         return; // channels is a multiple of VEC (checked by the host)
@@ -442,21 +467,21 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
     for (int e = 0; e < VEC; e++)
         load_state<R, M>(p, c0 + e, y1[e], y2[e], y3[e]);
 
-    R *col = p.data + c0;
+    S *col = p.data + c0;
     V cur[U], nxt[U];
     auto fetch = [&](V (&dst)[U], uint64_t s0) {
         if (s0 + U <= p.samples) { // whole batch inside the stream: no per-row predicates
-            R *row = col + s0 * p.stride;
+            S *row = col + s0 * p.stride;
 #pragma unroll
             for (int u = 0; u < U; u++)
-                dst[u] = gload_cv<R, VEC, NT>(row + u * p.stride);
+                dst[u] = gload_cv<S, VEC, NT>(row + u * p.stride);
             return;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             dst[u] = V{};
             if (s0 + u < p.samples)
-                dst[u] = gload_cv<R, VEC, NT>(col + (s0 + u) * p.stride);
+                dst[u] = gload_cv<S, VEC, NT>(col + (s0 + u) * p.stride);
         }
     };
     fetch(cur, 0);
@@ -464,13 +489,13 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
         if (s0 + U < p.samples)
             fetch(nxt, s0 + U);
         if (s0 + U <= p.samples) {
-            R *row = col + s0 * p.stride;
+            S *row = col + s0 * p.stride;
 #pragma unroll
             for (int u = 0; u < U; u++) {
 #pragma unroll
                 for (int e = 0; e < VEC; e++)
-                    cur[u].v[e] = cascade_step<R, KIND, M>(cur[u].v[e], p, y1[e], y2[e], y3[e]);
-                gstore_cv<R, VEC, NT>(row + u * p.stride, cur[u]);
+                    cur[u].v[e] = (S)cascade_step<R, KIND, M, P::fused>((R)cur[u].v[e], p, y1[e], y2[e], y3[e]);
+                gstore_cv<S, VEC, NT>(row + u * p.stride, cur[u]);
             }
         } else {
 #pragma unroll
@@ -478,8 +503,8 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
                 if (s0 + u < p.samples) {
 #pragma unroll
                     for (int e = 0; e < VEC; e++)
-                        cur[u].v[e] = cascade_step<R, KIND, M>(cur[u].v[e], p, y1[e], y2[e], y3[e]);
-                    gstore_cv<R, VEC, NT>(col + (s0 + u) * p.stride, cur[u]);
+                        cur[u].v[e] = (S)cascade_step<R, KIND, M, P::fused>((R)cur[u].v[e], p, y1[e], y2[e], y3[e]);
+                    gstore_cv<S, VEC, NT>(col + (s0 + u) * p.stride, cur[u]);
                 }
             }
         }
@@ -492,10 +517,11 @@ __global__ __launch_bounds__(64) void sdsp_iir_interleaved_kernel(iir_dev_args<R
         store_state<R, M>(p, c0 + e, y1[e], y2[e], y3[e]);
 }
 
-template <typename R, int M> iir_dev_args<R, M> make_args(const iir_args &a)
+template <typename P, int M> iir_dev_args<typename P::S, typename P::R, M> make_args(const iir_args &a)
 {
-    iir_dev_args<R, M> p;
-    p.data = reinterpret_cast<R *>(a.data);
+    using R = typename P::R;
+    iir_dev_args<typename P::S, R, M> p;
+    p.data = reinterpret_cast<typename P::S *>(a.data);
     p.state = reinterpret_cast<R *>(a.state);
     p.channels = a.channels;
     p.samples = a.samples;
@@ -510,11 +536,12 @@ template <typename R, int M> iir_dev_args<R, M> make_args(const iir_args &a)
     return p;
 }
 
-template <typename R, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
+template <typename P, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
 {
-    const auto p = make_args<R, M>(a);
-    const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(R)) % 16 == 0) &&
-                         ((a.samples * sizeof(R)) % 16 == 0);
+    const auto p = make_args<P, M>(a);
+    using S = typename P::S;
+    const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) &&
+                         ((a.samples * sizeof(S)) % 16 == 0);
     // variants (identical arithmetic, bit-identical results):
     //   0 super-tile, streaming accesses (default)   1 super-tile, default cache policy
     //   2 tiled 128-byte rows, streaming       3 direct (any alignment)       4 tiled 256-byte rows
@@ -523,35 +550,35 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
         variant = 3; // shapes the vector kernels cannot address fall to the direct kernel
     if (variant == 3) {
         const uint64_t blocks = (a.channels + 255) / 256;
-        hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((sdsp_iir_direct_kernel<P, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
     } else if (variant == 0 || variant == 1 || variant == 5 || variant == 6) {
         const uint64_t blocks = (a.channels + 63) / 64;
         if (blocks > 0x7fffffffull)
             return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
         const size_t lds = 64 * (128 + 16);
         if (variant == 0) // measured (f32, round 1): streaming 5.58 TB/s vs default policy 5.29 TB/s
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else if (variant == 1)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else if (variant == 5)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 3>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 3>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
         else
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<R, KIND, M, false, 2>), dim3((uint32_t)blocks), dim3(64), lds,
+            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 2>), dim3((uint32_t)blocks), dim3(64), lds,
                                stream, p);
     } else {
         const uint64_t blocks = (a.channels + 255) / 256;
         if (variant == 2) {
             constexpr int ROWB = 128;
             const size_t lds = 4 * 64 * (ROWB + 16);
-            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<R, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds,
+            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds,
                                stream, p);
         } else if (variant == 4) {
             constexpr int ROWB = 256;
             const size_t lds = 4 * 64 * (ROWB + 16);
-            auto kern = sdsp_iir_tiled_kernel<R, KIND, M, ROWB, true>;
+            auto kern = sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
             hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, stream, p);
@@ -566,39 +593,39 @@ template <typename R, int KIND, int M> int launch_km(const iir_args &a, int vari
 }
 
 // m_t = 10 .. 16 (the reference accepts any even M, casc_2o_iir.h:25): correct through the direct kernel, not tuned
-template <typename R, int KIND, int M> int launch_direct(const iir_args &a, hipStream_t stream)
+template <typename P, int KIND, int M> int launch_direct(const iir_args &a, hipStream_t stream)
 {
-    const auto p = make_args<R, M>(a);
+    const auto p = make_args<P, M>(a);
     const uint64_t blocks = (a.channels + 255) / 256;
-    hipLaunchKernelGGL((sdsp_iir_direct_kernel<R, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((sdsp_iir_direct_kernel<P, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
 
-template <typename R, int KIND> int launch_k(const iir_args &a, int variant, hipStream_t stream)
+template <typename P, int KIND> int launch_k(const iir_args &a, int variant, hipStream_t stream)
 {
     switch (a.sections) {
-    case 2: return launch_km<R, KIND, 2>(a, variant, stream);
-    case 4: return launch_km<R, KIND, 4>(a, variant, stream);
-    case 6: return launch_km<R, KIND, 6>(a, variant, stream);
-    case 8: return launch_km<R, KIND, 8>(a, variant, stream);
-    case 10: return launch_direct<R, KIND, 10>(a, stream);
-    case 12: return launch_direct<R, KIND, 12>(a, stream);
-    case 14: return launch_direct<R, KIND, 14>(a, stream);
-    case 16: return launch_direct<R, KIND, 16>(a, stream);
+    case 2: return launch_km<P, KIND, 2>(a, variant, stream);
+    case 4: return launch_km<P, KIND, 4>(a, variant, stream);
+    case 6: return launch_km<P, KIND, 6>(a, variant, stream);
+    case 8: return launch_km<P, KIND, 8>(a, variant, stream);
+    case 10: return launch_direct<P, KIND, 10>(a, stream);
+    case 12: return launch_direct<P, KIND, 12>(a, stream);
+    case 14: return launch_direct<P, KIND, 14>(a, stream);
+    case 16: return launch_direct<P, KIND, 16>(a, stream);
     default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be even and at most 16");
     }
 }
 
-template <typename R> int launch_r(const iir_args &a, int variant, hipStream_t stream)
+template <typename P> int launch_r(const iir_args &a, int variant, hipStream_t stream)
 {
     switch (a.kind) {
-    case SDSP_HIP_IIR_GENERIC: return launch_k<R, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
-    case SDSP_HIP_IIR_LP: return launch_k<R, SDSP_HIP_IIR_LP>(a, variant, stream);
-    case SDSP_HIP_IIR_HP: return launch_k<R, SDSP_HIP_IIR_HP>(a, variant, stream);
-    case SDSP_HIP_IIR_BP: return launch_k<R, SDSP_HIP_IIR_BP>(a, variant, stream);
+    case SDSP_HIP_IIR_GENERIC: return launch_k<P, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
+    case SDSP_HIP_IIR_LP: return launch_k<P, SDSP_HIP_IIR_LP>(a, variant, stream);
+    case SDSP_HIP_IIR_HP: return launch_k<P, SDSP_HIP_IIR_HP>(a, variant, stream);
+    case SDSP_HIP_IIR_BP: return launch_k<P, SDSP_HIP_IIR_BP>(a, variant, stream);
     default: return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
     }
 }
@@ -606,19 +633,20 @@ template <typename R> int launch_r(const iir_args &a, int variant, hipStream_t s
 
 namespace
 {
-template <typename R, int KIND, int M, int VEC, int U>
+template <typename P, int KIND, int M, int VEC, int U>
 int launch_il_v(const iir_args &a, bool nt, hipStream_t stream)
 {
-    if (((uintptr_t)a.data % (sizeof(R) * VEC)) || ((a.stride * sizeof(R)) % (sizeof(R) * VEC)) || (a.channels % VEC))
+    using S = typename P::S;
+    if (((uintptr_t)a.data % (sizeof(S) * VEC)) || ((a.stride * sizeof(S)) % (sizeof(S) * VEC)) || (a.channels % VEC))
         return fail(SDSP_HIP_ERR_INVALID_ARG, "interleaved layout: data/stride/channels must be multiples of the lane width");
-    const auto p = make_args<R, M>(a);
+    const auto p = make_args<P, M>(a);
     const uint64_t blocks = (a.channels / VEC + 63) / 64;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
     if (nt)
-        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<R, KIND, M, true, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<P, KIND, M, true, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
     else
-        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<R, KIND, M, false, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((sdsp_iir_interleaved_kernel<P, KIND, M, false, VEC, U>), dim3((uint32_t)blocks), dim3(64), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("iir interleaved launch: ") + hipGetErrorString(e));
@@ -627,45 +655,46 @@ int launch_il_v(const iir_args &a, bool nt, hipStream_t stream)
 // variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming, eight rows in
 // flight (measured 65.9 % of HBM peak, round 1; 4 = the same with four rows: 63.3 %); 1 = 8-byte lanes, streaming (58 %); 2 = 8-byte lanes,
 // default cache policy (57 %); 3 = 4-byte lanes, f32 only (58 %).  Narrower shapes fall through.
-template <typename R, int KIND, int M> int launch_il_km(const iir_args &a, int variant, hipStream_t stream)
+template <typename P, int KIND, int M> int launch_il_km(const iir_args &a, int variant, hipStream_t stream)
 {
-    constexpr int V8 = 8 / (int)sizeof(R), V16 = 16 / (int)sizeof(R);
-    const bool a16 = !((uintptr_t)a.data % 16) && !((a.stride * sizeof(R)) % 16) && !(a.channels % V16);
-    const bool a8 = !((uintptr_t)a.data % 8) && !((a.stride * sizeof(R)) % 8) && !(a.channels % V8);
+    using S = typename P::S;
+    constexpr int V8 = 8 / (int)sizeof(S), V16 = 16 / (int)sizeof(S);
+    const bool a16 = !((uintptr_t)a.data % 16) && !((a.stride * sizeof(S)) % 16) && !(a.channels % V16);
+    const bool a8 = !((uintptr_t)a.data % 8) && !((a.stride * sizeof(S)) % 8) && !(a.channels % V8);
     if (variant == 0 && a16)
-        return launch_il_v<R, KIND, M, V16, 8>(a, true, stream);
+        return launch_il_v<P, KIND, M, V16, 8>(a, true, stream);
     if (variant == 4 && a16) // 16-byte lanes, four rows in flight per wave (the default until U = 8 measured +2.6 points)
-        return launch_il_v<R, KIND, M, V16, 4>(a, true, stream);
-    if constexpr (sizeof(R) == 4) {
+        return launch_il_v<P, KIND, M, V16, 4>(a, true, stream);
+    if constexpr (sizeof(S) == 4) {
         if (variant == 3 || !a8)
-            return launch_il_v<R, KIND, M, 1, 8>(a, true, stream);
+            return launch_il_v<P, KIND, M, 1, 8>(a, true, stream);
     }
     if (a8)
-        return launch_il_v<R, KIND, M, V8, 8>(a, variant != 2, stream);
+        return launch_il_v<P, KIND, M, V8, 8>(a, variant != 2, stream);
     return fail(SDSP_HIP_ERR_INVALID_ARG, "interleaved layout needs 8-byte aligned rows");
 }
-template <typename R, int KIND> int launch_il_k(const iir_args &a, int variant, hipStream_t stream)
+template <typename P, int KIND> int launch_il_k(const iir_args &a, int variant, hipStream_t stream)
 {
     switch (a.sections) {
-    case 2: return launch_il_km<R, KIND, 2>(a, variant, stream);
-    case 4: return launch_il_km<R, KIND, 4>(a, variant, stream);
-    case 6: return launch_il_km<R, KIND, 6>(a, variant, stream);
-    case 8: return launch_il_km<R, KIND, 8>(a, variant, stream);
+    case 2: return launch_il_km<P, KIND, 2>(a, variant, stream);
+    case 4: return launch_il_km<P, KIND, 4>(a, variant, stream);
+    case 6: return launch_il_km<P, KIND, 6>(a, variant, stream);
+    case 8: return launch_il_km<P, KIND, 8>(a, variant, stream);
     // m_t = 10 .. 16: one channel per lane, four rows in flight (correct, not tuned)
-    case 10: return launch_il_v<R, KIND, 10, 1, 4>(a, true, stream);
-    case 12: return launch_il_v<R, KIND, 12, 1, 4>(a, true, stream);
-    case 14: return launch_il_v<R, KIND, 14, 1, 4>(a, true, stream);
-    case 16: return launch_il_v<R, KIND, 16, 1, 4>(a, true, stream);
+    case 10: return launch_il_v<P, KIND, 10, 1, 4>(a, true, stream);
+    case 12: return launch_il_v<P, KIND, 12, 1, 4>(a, true, stream);
+    case 14: return launch_il_v<P, KIND, 14, 1, 4>(a, true, stream);
+    case 16: return launch_il_v<P, KIND, 16, 1, 4>(a, true, stream);
     default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "sections must be even and at most 16");
     }
 }
-template <typename R> int launch_il_r(const iir_args &a, int variant, hipStream_t stream)
+template <typename P> int launch_il_r(const iir_args &a, int variant, hipStream_t stream)
 {
     switch (a.kind) {
-    case SDSP_HIP_IIR_GENERIC: return launch_il_k<R, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
-    case SDSP_HIP_IIR_LP: return launch_il_k<R, SDSP_HIP_IIR_LP>(a, variant, stream);
-    case SDSP_HIP_IIR_HP: return launch_il_k<R, SDSP_HIP_IIR_HP>(a, variant, stream);
-    case SDSP_HIP_IIR_BP: return launch_il_k<R, SDSP_HIP_IIR_BP>(a, variant, stream);
+    case SDSP_HIP_IIR_GENERIC: return launch_il_k<P, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
+    case SDSP_HIP_IIR_LP: return launch_il_k<P, SDSP_HIP_IIR_LP>(a, variant, stream);
+    case SDSP_HIP_IIR_HP: return launch_il_k<P, SDSP_HIP_IIR_HP>(a, variant, stream);
+    case SDSP_HIP_IIR_BP: return launch_il_k<P, SDSP_HIP_IIR_BP>(a, variant, stream);
     default: return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
     }
 }
@@ -677,7 +706,9 @@ int launch_iir_interleaved(int precision, const iir_args &a, int variant, void *
     if (a.channels == 0 || a.samples == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return precision == SDSP_HIP_F64 ? launch_il_r<double>(a, variant, s) : launch_il_r<float>(a, variant, s);
+    if (precision == SDSP_HIP_F32_F64STATE)
+        return launch_il_r<prec_mix>(a, variant, s);
+    return precision == SDSP_HIP_F64 ? launch_il_r<prec_f64>(a, variant, s) : launch_il_r<prec_f32>(a, variant, s);
 }
 
 int launch_iir(int precision, const iir_args &a, int variant, void *stream)
@@ -687,6 +718,8 @@ int launch_iir(int precision, const iir_args &a, int variant, void *stream)
     if ((a.channels + 255) / 256 > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return precision == SDSP_HIP_F64 ? launch_r<double>(a, variant, s) : launch_r<float>(a, variant, s);
+    if (precision == SDSP_HIP_F32_F64STATE)
+        return launch_r<prec_mix>(a, variant, s);
+    return precision == SDSP_HIP_F64 ? launch_r<prec_f64>(a, variant, s) : launch_r<prec_f32>(a, variant, s);
 }
 } // namespace sdsp_hip

@@ -96,6 +96,19 @@ int launch_fft_reg_f64(const fft_reg_args &a, void *stream);
 bool fft_big_supports(uint32_t n, int radix);
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 
+// N = 8192 / 16384, f32: one leading radix-2 / radix-4 stage + the tuned N = 4096 radix-4 machinery (fft_mix.hip)
+struct fft_mix_args {
+    void *data;
+    const void *tw;      // sub-transform thread-twiddle table (layout of the N = 4096 radix-4 kernel's)
+    const void *tw_lead; // [q - 1][t] = W_N^(q t), q < R, t < 256
+    uint32_t n;
+    uint64_t batch;
+    float scale;
+    int reverse;
+};
+bool fft_mix_supports(uint32_t n);
+int launch_fft_mix_f32(const fft_mix_args &a, void *stream);
+
 // N = 2^16 .. 2^19, f32: the two streaming passes around 16 x batch row transforms (fft_mid.hip)
 int launch_fft_mid_cols(int precision, const void *in, void *out, const void *tw, uint32_t n2, uint64_t batch, int reverse,
                         void *stream);

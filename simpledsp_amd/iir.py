@@ -31,6 +31,12 @@ class casc_2o_iir:
         self._state = None  # torch tensor (3*(m_t+1), channels) on the device, or None = zeros
         self._variant = 0
 
+    def _dtypes(self):
+        """(sample dtype, state dtype): F32_F64STATE keeps float samples and a double recurrence"""
+        import torch
+        return (torch.float64 if self.precision == L.F64 else torch.float32,
+                torch.float32 if self.precision == L.F32 else torch.float64)
+
     # ---- coefficient design (host, double): casc_2o_iir.h:82-194
     def _designed(self, f_type):
         self.m_f_type = f_type
@@ -76,7 +82,7 @@ class casc_2o_iir:
         mem = np.zeros((self.m_t + 1, 3))
         L.check(self._lib.sdsp_hip_iir_preload(self.m_t, self.m_f_type, self.m_a_coeff.ctypes.data,
                                                self.m_b_coeff.ctypes.data, self.m_gain, value, mem.ctypes.data))
-        dt = torch.float64 if self.precision == L.F64 else torch.float32
+        dt = self._dtypes()[1]
         col = torch.from_numpy(mem.reshape(-1).copy()).to(dt)
         self._state = col[:, None].expand(-1, self.channels).contiguous().to(f"cuda:{self.device}")
 
@@ -113,7 +119,7 @@ class casc_2o_iir:
         """data: contiguous device tensor (channels, stride); filters data[:, offset:offset+samples]
         of every channel in place, continuing from the bank's state."""
         import torch
-        dt = torch.float64 if self.precision == L.F64 else torch.float32
+        dt, st = self._dtypes()
         if data.dtype != dt or not data.is_cuda or not data.is_contiguous() or data.dim() != 2:
             raise ValueError("process needs a contiguous (channels, samples) device tensor of the bank dtype")
         if data.shape[0] != self.channels:
@@ -126,7 +132,7 @@ class casc_2o_iir:
             raise ValueError("block exceeds the row")
         self._ensure_plan()
         if self._state is None:
-            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=f"cuda:{self.device}")
+            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=st, device=f"cuda:{self.device}")
         stream = torch.cuda.current_stream(data.device).cuda_stream
         L.check(self._lib.sdsp_hip_iir_process(self._plan, data.data_ptr() + offset * data.element_size(),
                                                self.channels, samples, stride, self._state.data_ptr(), stream))
@@ -137,7 +143,7 @@ class casc_2o_iir:
         (SURVEY 8f-2).  Filters rows offset..offset+samples in place, continuing from the bank's
         state; bit-identical to process() on the transposed data, without any transpose."""
         import torch
-        dt = torch.float64 if self.precision == L.F64 else torch.float32
+        dt, st = self._dtypes()
         if data.dtype != dt or not data.is_cuda or not data.is_contiguous() or data.dim() != 2:
             raise ValueError("process_interleaved needs a contiguous (samples, channels) device tensor")
         if data.shape[1] != self.channels:
@@ -149,7 +155,7 @@ class casc_2o_iir:
             raise ValueError("block exceeds the buffer")
         self._ensure_plan()
         if self._state is None:
-            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=dt, device=f"cuda:{self.device}")
+            self._state = torch.zeros((3 * (self.m_t + 1), self.channels), dtype=st, device=f"cuda:{self.device}")
         stream = torch.cuda.current_stream(data.device).cuda_stream
         L.check(self._lib.sdsp_hip_iir_process_interleaved(
             self._plan, data.data_ptr() + offset * self.channels * data.element_size(), self.channels, samples,

@@ -74,17 +74,19 @@ for case in range(cases):
                 desc = f"rfft n_real={n_real} r{radix} batch={batch}"
         elif kind == "iir":
             m = int(rng.choice([2, 4, 6, 8]))
-            f64 = rng.random() < 0.5
+            mode = int(rng.integers(0, 3))  # 0 f32, 1 f64, 2 float samples + double recurrence (SDSP_HIP_F32_F64STATE)
+            f64, mixed = mode == 1, mode == 2
             channels = int(rng.integers(1, 400))
             samples = int(rng.integers(1, 700))
             pad = int(rng.choice([0, 0, 1, 3, 4, 16]))
             off = int(rng.integers(0, pad + 1))
             ftype = int(rng.integers(1, 5))
             spec_kind = ftype if (ftype < 4 and rng.random() < 0.5) else sd.IIR_GENERIC
-            bank = sd.casc_2o_iir(m, channels, sd.F64 if f64 else sd.F32, spec_kind)
-            # f32 recursions lose accuracy as the poles approach z = 1 (1.3e-4 at f0/fs = 200/39000): the
-            # f32 cases stay in the BASELINE filter's neighbourhood, the f64 cases (bit-exact) roam
-            args = (float(rng.uniform(500, 20e3) if f64 else rng.uniform(8e3, 20e3)), 100e3)
+            bank = sd.casc_2o_iir(m, channels, (sd.F32, sd.F64, sd.F32_F64STATE)[mode], spec_kind)
+            # f32 recursions lose accuracy as the poles approach z = 1 (1.3e-4 at f0/fs = 200/39000): the pure
+            # f32 cases stay in the BASELINE filter's neighbourhood; the f64 cases (bit-exact) and the mixed mode (float
+            # samples, double recurrence: 1e-6 everywhere) roam over f0 in [500, 20k]
+            args = (float(rng.uniform(8e3, 20e3) if mode == 0 else rng.uniform(500, 20e3)), 100e3)
             {1: lambda: bank.set_lp_coeff(*args), 2: lambda: bank.set_hp_coeff(*args), 3: lambda: bank.set_bp_coeff(*args, 1.3),
              4: lambda: bank.set_bs_coeff(*args, 1.3)}[ftype]()
             bank.set_variant(int(rng.integers(0, 7)))
@@ -121,8 +123,9 @@ for case in range(cases):
                 # untouched padding stays untouched
                 if not np.array_equal(got[c, :off], x[c, :off]) or not np.array_equal(got[c, off + samples:], x[c, off + samples:]):
                     err = 9.0
-            tol = 0.5 if f64 else 3e-6  # 8 sections accumulate more rounding than the 4 of the BASELINE filter (1e-6)
-            desc = f"iir{' wire' if wire else ''} m={m} {'f64' if f64 else 'f32'} ch={channels} n={samples} pad={pad} off={off} type={ftype} kind={spec_kind} var={bank._variant}"
+            # pure f32: 8 sections accumulate more rounding than the 4 of the BASELINE filter (1e-6); mixed: one float rounding
+            tol = 0.5 if f64 else 1e-6 if mixed else 3e-6
+            desc = f"iir{' wire' if wire else ''} m={m} {('f32', 'f64', 'f32+f64state')[mode]} ch={channels} n={samples} pad={pad} off={off} type={ftype} kind={spec_kind} var={bank._variant}"
         else:
             taps = int(rng.integers(1, 200))
             f64 = rng.random() < 0.5

@@ -128,11 +128,12 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        big = n >= 8192  # registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there (radix-4 16384 too)
-        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else
+        big = n >= 8192  # radix 2: registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
+        mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
+        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
                                              "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
         outs = []
-        # streaming / default policy / coverage kernel (/ tuned r2 or large-transform kernel)
+        # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel (, the size's tuned kernel)
         for variant in ((2, 1, 99, 0) if (n, radix) == (4096, 2) or big else (0, 1, 99)):
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
@@ -142,7 +143,47 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
             outs.append(d.cpu().numpy())
             assert rel_max_err(outs[-1], want) < TOL32, (n, radix, rev, variant, rel_max_err(outs[-1], want))
             assert bool((guard == 7.0 + 3.0j).all())
-        assert np.array_equal(outs[0], outs[1])
+        if not mix:
+            assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,radix,ref_radix", [(8192, 0, 2), (16384, 4, 4), (16384, 0, 4)])
+@pytest.mark.parametrize("batch", [1, 5, 300])
+def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch):
+    """csrc/fft_mix.hip: N = 2 * 4^6 through the radix-4 kernel with one radix-2 stage (plans of radix AUTO),
+    N = 4^7 with genuine radix-4 stages (sdsp::fft_radix4<T,16384>, fft.h:301-360).  Against the oracle's algorithm of the
+    stage type the plan reports, against the radix-2-stage kernel (variant 1) on every transform, both directions, and
+    the round trip."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n + batch + radix)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    pick = sorted({0, batch - 1, batch // 2})
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
+        assert plan.info.kernel.decode() == "sdsp_fft_mix_f32" and plan.info.hbm_passes == 1 and plan.info.radix == ref_radix
+        d = torch.from_numpy(x).cuda()
+        guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
+        plan.exec(d)
+        torch.cuda.synchronize()
+        got = d.cpu().numpy()
+        assert bool((guard == 7.0 + 3.0j).all())
+        want = oracle.fft(x[pick].astype(np.complex128), ref_radix, rev)
+        assert rel_max_err(got[pick], want) < TOL32, rel_max_err(got[pick], want)
+        plan.set_variant(1)
+        assert plan.info.kernel.decode() == "sdsp_fft_big_kernel"
+        d2 = torch.from_numpy(x).cuda()
+        plan.exec(d2)
+        torch.cuda.synchronize()
+        assert rel_max_err(got, d2.cpu().numpy().astype(np.complex128)) < TOL32
+    fwd = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=batch)
+    inv = sd.FftPlan(n, radix, sd.reverse_fft, sd.F32, max_batch=batch)
+    d = torch.from_numpy(x).cuda()
+    fwd.exec(d)
+    inv.exec(d)
+    torch.cuda.synchronize()
+    assert rel_max_err(d.cpu().numpy(), x) < TOL32
+    # an explicit radix 2 is honoured: radix-2 butterflies only
+    assert sd.FftPlan(n, 2, sd.forward_fft, sd.F32).info.kernel.decode() == "sdsp_fft_big_kernel"
 
 
 @pytest.mark.parametrize("batch", [1, 3, 255, 2049])

@@ -38,7 +38,7 @@ def _bank(sd, m, channels, precision, kind, ftype, f0, fs, q, gain_in=1.0, varia
 
 
 def _process(torch, bank, x, **kw):
-    dt = torch.float64 if bank.precision == 1 else torch.float32
+    dt = torch.float64 if bank.precision == 1 else torch.float32  # F32 and F32_F64STATE store floats
     d = torch.from_numpy(np.ascontiguousarray(x)).to(dt).cuda()
     bank.process(d, **kw)
     torch.cuda.synchronize()
@@ -163,6 +163,51 @@ def test_f32_bank_against_oracle(sd, torch_cuda, oracle, channels, samples):
         assert rel_max_err(results[0][c], want) < 1e-6, (c, rel_max_err(results[0][c], want))
     # all kernel variants run the same arithmetic in the same order
     assert all(np.array_equal(results[0], results[v]) for v in (1, 2, 3, 4, 5, 6))
+
+
+@pytest.mark.parametrize("csv", impulse_csvs(), ids=lambda p: p.stem)
+def test_mixed_precision_octave_impulse_responses(sd, torch_cuda, csv):
+    """SDSP_HIP_F32_F64STATE: float samples (the f32 kernels' 8 bytes per sample), double state and recurrence.  The 9
+    Octave fixtures (testIIR.cpp:32-75) -- which the pure f32 kernels miss by up to 1.3e-4 at f0/fs = 200/39000 -- to float
+    rounding; block streaming bit-identical; the sample-major layout bit-identical."""
+    ftype, fs, f0, q, want = read_impulse_csv(csv)
+    x = np.zeros((70, want.size), np.float32)
+    x[:, 0] = 1.0
+    for kind in (sd.IIR_GENERIC, ftype):
+        bank = _bank(sd, 4, 70, sd.F32_F64STATE, kind, ftype, f0, fs, q)
+        out = _process(torch_cuda, bank, x)
+        assert out.dtype == np.float32
+        assert rel_max_err(out[33], want) < 1.2e-7, rel_max_err(out[33], want)  # one rounding to float: 2^-24 = 6e-8
+        bank2 = _bank(sd, 4, 70, sd.F32_F64STATE, kind, ftype, f0, fs, q)
+        d = torch_cuda.from_numpy(x.copy()).cuda()
+        for off in range(0, want.size, 32):
+            bank2.process(d, samples=min(32, want.size - off), offset=off)
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), out)
+        assert bank2.state.dtype == torch_cuda.float64
+        bank3 = _bank(sd, 4, 70, sd.F32_F64STATE, kind, ftype, f0, fs, q)
+        dw = torch_cuda.from_numpy(np.ascontiguousarray(x.T)).cuda()
+        bank3.process_interleaved(dw)
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(dw.cpu().numpy().T, out)
+
+
+def test_mixed_precision_random_input_and_variants(sd, torch_cuda, oracle):
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((300, 4096)).astype(np.float32)
+    for f0 in (10e3, 500.0):  # the BASELINE filter, and a low cutoff where an f32 recurrence is off by 1e-4
+        fo = oracle.iir(4)
+        fo.set_lp_coeff(f0, 100e3)
+        want = fo.process(x[7].astype(np.float64))
+        outs = []
+        for variant in (0, 1, 2, 3):
+            bank = _bank(sd, 4, 300, sd.F32_F64STATE, sd.IIR_GENERIC, 1, f0, 100e3, 0.0, variant=variant)
+            outs.append(_process(torch_cuda, bank, x))
+            assert rel_max_err(outs[-1][7], want) < 1.2e-7, (f0, variant, rel_max_err(outs[-1][7], want))
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+        f32 = _process(torch_cuda, _bank(sd, 4, 300, sd.F32, sd.IIR_GENERIC, 1, f0, 100e3, 0.0), x)
+        if f0 == 500.0:  # what the mode is for
+            assert rel_max_err(f32[7], want) > 20 * rel_max_err(outs[0][7], want)
 
 
 def test_f32_specialised_kinds_and_streaming(sd, torch_cuda, oracle):
