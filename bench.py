@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_lp|iir_il]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_mix|iir_lp|iir_il]
     python bench.py --workload fft --n 8192 --radix 2 [--precision f64]     (any covered size; not a BASELINE config)
     python bench.py --workload fir --taps 32                                  (FIR bank; not a BASELINE config)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_il", "fft", "fir"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_mix", "iir_il", "fft", "fir"])
     ap.add_argument("--n", type=int, default=1024, help="--workload fft: transform size")
     ap.add_argument("--radix", type=int, default=2, help="--workload fft: 2 or 4")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / fir")
@@ -169,14 +169,15 @@ def make_fir(sd, torch, dev, args):
             args.precision, (bank, x))
 
 
-def make_iir(sd, torch, dev, args, f64=False, interleaved=False, lp_class=False):
+def make_iir(sd, torch, dev, args, f64=False, interleaved=False, lp_class=False, mixed=False):
     channels = args.batch_per_gpu or (1 << 20)
     samples = 4096
     dt = torch.float64 if f64 else torch.float32
     g = torch.Generator(device=dev).manual_seed(0x5D5B + 2 + dev.index)
     x = torch.randn((samples, channels) if interleaved else (channels, samples), generator=g, device=dev, dtype=dt)
     # casc_2o_iir<4> (testIIR.cpp:465-487) or the numerator-folded casc_2o_iir_lp<4> (:489-494)
-    bank = sd.casc_2o_iir(4, channels, sd.F64 if f64 else sd.F32, sd.IIR_LP if lp_class else sd.IIR_GENERIC, device=dev.index)
+    prec = sd.F64 if f64 else sd.F32_F64STATE if mixed else sd.F32
+    bank = sd.casc_2o_iir(4, channels, prec, sd.IIR_LP if lp_class else sd.IIR_GENERIC, device=dev.index)
     bank.set_lp_coeff(10e3, 100e3)  # testIIR.cpp:469-474
     if args.variant >= 0:
         bank.set_variant(args.variant)
@@ -195,10 +196,11 @@ def make_iir(sd, torch, dev, args, f64=False, interleaved=False, lp_class=False)
         "sections": 4, "class": "casc_2o_iir_lp" if lp_class else "casc_2o_iir", "channels_per_gpu": channels, "samples": samples,
         "kernel": "sdsp_iir_interleaved_kernel" if interleaved else "sdsp_iir_supertile_kernel",
         "layout": "sample-major [sample][channel] (SURVEY 8f-2)" if interleaved else "channel-major (BASELINE)",
+        "arithmetic": "float samples, double state and recurrence (SDSP_HIP_F32_F64STATE)" if mixed else ("f64" if f64 else "f32"),
     }
     unit_bytes = 16 if f64 else 8
     metric = "IIR samples/sec (4 cascaded biquads, LP" + (", casc_2o_iir_lp class)" if lp_class else ")")
-    return step, channels * samples, unit_bytes, desc, metric, "samples/s", "f64" if f64 else "f32", (bank, x)
+    return step, channels * samples, unit_bytes, desc, metric, "samples/s", "f64" if f64 else "f32+f64state" if mixed else "f32", (bank, x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -268,15 +270,22 @@ def cpu_baseline(workload: str, seconds: float):
             "sample": sample + f"; {cores} threads, float64 (the reference's precision)"}
 
 
-def read_traffic(kernels: str):
-    """HBM bytes per step from the committed PMC summary (profiles/traffic.json), or None.
-    `kernels` may name several kernels joined by '+' (multi-pass paths): their traffic is summed."""
+def read_traffic(kernels: str, algorithmic_bytes: float):
+    """HBM bytes per step from the committed PMC summary (profiles/traffic.json), or None: the measured traffic /
+    algorithmic-bytes ratio of the profiled launch of this kernel, applied to this step's algorithmic bytes (the same
+    kernel serves other batch sizes and sample types).  `kernels` may name several kernels joined by '+' (multi-pass
+    paths): each moves the step's bytes once, their traffic is summed."""
     p = ROOT / "profiles" / "traffic.json"
     try:
         t = json.loads(p.read_text())
         total = 0.0
         for name in kernels.split("+"):
-            total += t[name]["hbm_bytes_per_launch"] * t[name].get("launches_per_step", 1)
+            e = t[name]
+            alg = e.get("algorithmic_bytes_per_launch")
+            if alg:
+                total += e["hbm_bytes_per_launch"] / alg * algorithmic_bytes
+            else:  # entries of round 1: absolute bytes of the BASELINE shape
+                total += e["hbm_bytes_per_launch"] * e.get("launches_per_step", 1)
         return total
     except Exception:
         return None
@@ -286,6 +295,7 @@ WORKLOADS = {
     "fft4096": make_fft4096, "fft1m": make_fft1m, "iir": make_iir,
     "iir64": lambda *a: make_iir(*a, f64=True),
     "iir_lp": lambda *a: make_iir(*a, lp_class=True),
+    "iir_mix": lambda *a: make_iir(*a, mixed=True),
     "iir_il": lambda *a: make_iir(*a, interleaved=True), "fft": make_fft, "fir": make_fir,
 }
 
@@ -326,7 +336,7 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
         "config": {**desc, "parallelism": f"batch-shard x{world}, no collective"},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"]),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"], units * unit_bytes),
             "traffic_source": "committed PMC summary profiles/traffic.json (separate rocprofv3 --pmc passes), not this run",
             "kernel": desc["kernel"], "avg_launch_ms": kern_ms,
             "algorithmic_bytes_per_launch": units * unit_bytes,
@@ -369,7 +379,7 @@ def main():
     # the other single-GPU BASELINE configs, same K / W, appended to the same line (N = 1, default workload only)
     others = []
     if world == 1 and args.workload == "fft4096" and not args.no_other_configs and not args.batch_per_gpu and args.variant < 0:
-        plan = [("fft1m", 0), ("iir", 0), ("iir64", 0), ("iir_lp", 0), ("fft4096", 262144)]
+        plan = [("fft1m", 0), ("iir", 0), ("iir64", 0), ("iir_mix", 0), ("iir_lp", 0), ("fft4096", 262144)]
         for name, batch in plan:
             args.batch_per_gpu = batch
             r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
@@ -395,7 +405,7 @@ def main():
             for name, r in others:
                 # the cfg-5 shard shares the headline's CPU leg; iir64 shares iir's (the reference computes in double anyway)
                 if not args.no_cpu_baseline and name != "fft4096":
-                    key = "iir" if name == "iir64" else name
+                    key = "iir" if name in ("iir64", "iir_mix") else name
                     if key not in cpu_cache:
                         cpu_cache[key] = cpu_baseline(key, args.other_cpu_seconds)
                     r["cpu_baseline"] = dict(cpu_cache[key])

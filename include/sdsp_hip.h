@@ -103,8 +103,10 @@ int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
 /*
  * Replaces sdsp::fft_radix2<T,N> (fft.h:258-299, radix = 2, n a power of 2) and
  * sdsp::fft_radix4<T,N> (fft.h:301-360, radix = 4, n a power of 4) for a BATCH of transforms.
- * radix = SDSP_HIP_RADIX_AUTO (0) picks radix 4 when n is a power of 4 and radix 2 otherwise (any power of
- * two through one entry).
+ * An explicit radix is the stage type that runs (2: radix-2 butterflies only; 4: radix-4 butterflies only).
+ * radix = SDSP_HIP_RADIX_AUTO (0) asks for the fastest kernel of the size: any power of two through one entry; at
+ * n = 8192 = 2 * 4^6 (f32) that is the radix-4 kernel behind ONE radix-2 stage, the mixed-radix case of SURVEY 8(f)-4
+ * (plan info then reports radix 2 and kernel "sdsp_fft_mix_f32").
  * n must satisfy the radix (else SDSP_HIP_ERR_INVALID_SIZE -- the run-time form of the
  * reference's static_asserts).  `max_batch` sizes the plan-owned workspace that transforms too
  * large for on-chip memory need (n > 16384 in f32, n > 8192 in f64); larger batches are

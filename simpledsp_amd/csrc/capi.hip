@@ -566,7 +566,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     if (radix_auto) {
         if (!sdsp_hip_is_power_of_2(n))
             return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
-        radix = sdsp_hip_is_power_of_4(n) ? 4 : 2;
+        // the stage type of the fastest kernel of the size: radix 4 where n is a power of 4 -- except n = 16384, where the
+        // radix-2-stage kernel (fft_big.hip, 59 % of HBM peak) beats the radix-4 one (fft_mix.hip at 2 workgroups per CU, 46 %)
+        radix = (sdsp_hip_is_power_of_4(n) && n != 16384) ? 4 : 2;
     }
     // the reference's static_asserts (fft.h:261, :304) as run-time checks
     if (radix == 2) {
@@ -595,8 +597,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     p->device = device;
     p->max_batch = max_batch ? max_batch : 1;
     // An explicit radix is the stage type that runs (radix 2: radix-2 butterflies only; radix 4: radix-4 only).  AUTO asks
-    // for the fastest kernel: at N = 2 * 4^k that is the radix-4 machinery behind ONE radix-2 stage.
-    p->allow_mix = radix_auto || radix == 4;
+    // for the fastest kernel: at N = 8192 = 2 * 4^6 that is the radix-4 machinery behind ONE radix-2 stage.
+    p->allow_mix = (radix_auto && n == 8192) || radix == 4;
 
     int rc = SDSP_HIP_OK;
     std::vector<double> w;

@@ -24,7 +24,7 @@ out.mkdir(exist_ok=True)
 
 def short(name: str) -> str:
     name = re.sub(r"^void ", "", name)
-    name = name.replace("sdsp_hip::(anonymous namespace)::", "")
+    name = name.replace("sdsp_hip::(anonymous namespace)::", "").replace("sdsp_hip::fft1m::", "").replace("sdsp_hip::fft4096::", "")
     name = re.sub(r"\(.*$", "", name)
     return name[:120]
 
@@ -83,7 +83,7 @@ for k, c in pm.items():
     b = (2 * f + wv) * 1024
     traffic[k] = {"hbm_bytes_per_launch": b, "fetch_size_kib_raw": f, "write_size_kib": wv, "profile": tag}
     lines.append(f"| `{k}` | {f:.1f} | {wv:.1f} | {b:.4g} |")
-# launches of each kernel per bench step: 1, except the chunked N=2^20 path (256 transforms per step
+# launches of each kernel per bench step: 1, except the chunked variant of the N=2^20 path (256 transforms per step
 # in chunks of 32 -> 8 launches of each pass, csrc/capi.hip)
 LAUNCHES_PER_STEP = {"sdsp_fft1m_cols": 8, "sdsp_fft1m_rows": 8}
 for k in traffic:
@@ -105,6 +105,9 @@ for k, v in traffic.items():
     merged.setdefault(k.split("<")[0], []).append(v)
 for k, vs in merged.items():
     allt[k] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in vs) / len(vs),
+               # the profiled workload's algorithmic bytes per launch of this kernel: bench.py scales the measured
+               # traffic / algorithmic ratio to the launch it reports (same kernel, other batch or sample type)
+               "algorithmic_bytes_per_launch": (alg / vs[0]["launches_per_step"]) if alg else None,
                "fetch_size_kib_raw": sum(v["fetch_size_kib_raw"] for v in vs) / len(vs),
                "write_size_kib": sum(v["write_size_kib"] for v in vs) / len(vs),
                "launches_per_step": vs[0]["launches_per_step"], "profile": tag}

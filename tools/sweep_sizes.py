@@ -9,11 +9,13 @@ import simpledsp_amd as sd
 dev = torch.device("cuda:0")
 total = 1 << 27  # complex elements = 1 GiB
 buf = torch.view_as_complex(torch.randn((total, 2), device=dev))
-sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [64, 256, 1024, 2048, 4096, 8192, 16384, 65536]
+sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
 for n in sizes:
-    for radix in (2, 4):
+    for radix in (2, 4, 0):  # 0 = SDSP_HIP_RADIX_AUTO: the fastest kernel of the size (mixed radix at N = 2 * 4^k)
         if radix == 4 and not sd.isPowerOf4(n):
             continue
+        if radix == 0 and n not in (8192, 16384):
+            continue  # elsewhere AUTO is one of the two above
         batch = total // n
         x = buf.view(batch, n)
         fwd = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=min(batch, 64))
