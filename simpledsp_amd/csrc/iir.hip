@@ -543,48 +543,27 @@ template <typename P, int KIND, int M> int launch_km(const iir_args &a, int vari
     const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) &&
                          ((a.samples * sizeof(S)) % 16 == 0);
     // variants (identical arithmetic, bit-identical results):
-    //   0 super-tile, streaming accesses (default)   1 super-tile, default cache policy
-    //   2 tiled 128-byte rows, streaming       3 direct (any alignment)       4 tiled 256-byte rows
-    //   5 super-tile of 3 sub-tiles (384 B bursts, 3 waves/SIMD)   6 of 2 sub-tiles (256 B, 4 waves/SIMD)
-    if (variant != 3 && !aligned)
-        variant = 3; // shapes the vector kernels cannot address fall to the direct kernel
-    if (variant == 3) {
+    //   0 super-tile, streaming accesses (default)   1 tiled, 128-byte rows, four waves per workgroup   2 direct (any alignment)
+    // Measured and dropped (round 1, BASELINE config 4, f32): super-tile with the default cache policy 66 % (0: 70 %), of 3 / 2
+    // sub-tiles (384- / 256-byte bursts) 61.9 / 58.8 %, tiled with 256-byte rows 56 %.
+    if (variant != 2 && !aligned)
+        variant = 2; // shapes the vector kernels cannot address fall to the direct kernel
+    if (variant == 2) {
         const uint64_t blocks = (a.channels + 255) / 256;
         hipLaunchKernelGGL((sdsp_iir_direct_kernel<P, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
-    } else if (variant == 0 || variant == 1 || variant == 5 || variant == 6) {
+    } else if (variant == 0) {
         const uint64_t blocks = (a.channels + 63) / 64;
         if (blocks > 0x7fffffffull)
             return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
         const size_t lds = 64 * (128 + 16);
-        if (variant == 0) // measured (f32, round 1): streaming 5.58 TB/s vs default policy 5.29 TB/s
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds,
-                               stream, p);
-        else if (variant == 1)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 4>), dim3((uint32_t)blocks), dim3(64), lds,
-                               stream, p);
-        else if (variant == 5)
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 3>), dim3((uint32_t)blocks), dim3(64), lds,
-                               stream, p);
-        else
-            hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, false, 2>), dim3((uint32_t)blocks), dim3(64), lds,
-                               stream, p);
-    } else {
+        hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
+    } else if (variant == 1) {
         const uint64_t blocks = (a.channels + 255) / 256;
-        if (variant == 2) {
-            constexpr int ROWB = 128;
-            const size_t lds = 4 * 64 * (ROWB + 16);
-            hipLaunchKernelGGL((sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds,
-                               stream, p);
-        } else if (variant == 4) {
-            constexpr int ROWB = 256;
-            const size_t lds = 4 * 64 * (ROWB + 16);
-            auto kern = sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, stream, p);
-        } else {
-            return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
-        }
+        constexpr int ROWB = 128;
+        const size_t lds = 4 * 64 * (ROWB + 16);
+        hipLaunchKernelGGL((sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds, stream, p);
+    } else {
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -652,25 +631,25 @@ int launch_il_v(const iir_args &a, bool nt, hipStream_t stream)
         return fail(SDSP_HIP_ERR_HIP, std::string("iir interleaved launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
-// variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming, eight rows in
-// flight (measured 65.9 % of HBM peak, round 1; 4 = the same with four rows: 63.3 %); 1 = 8-byte lanes, streaming (58 %); 2 = 8-byte lanes,
-// default cache policy (57 %); 3 = 4-byte lanes, f32 only (58 %).  Narrower shapes fall through.
+// variants: 0 = 16-byte lanes (4 f32 / 2 f64 channels per lane) when the shape allows, streaming, eight rows in flight
+// (65.9 % of HBM peak, round 1); 1 = 8-byte lanes (58 %); 2 = 4-byte lanes, f32 only (58 %).  Narrower shapes fall through.
+// Measured and dropped: four rows in flight 63.3 %, 8-byte lanes with the default cache policy 57 %.
 template <typename P, int KIND, int M> int launch_il_km(const iir_args &a, int variant, hipStream_t stream)
 {
     using S = typename P::S;
     constexpr int V8 = 8 / (int)sizeof(S), V16 = 16 / (int)sizeof(S);
     const bool a16 = !((uintptr_t)a.data % 16) && !((a.stride * sizeof(S)) % 16) && !(a.channels % V16);
     const bool a8 = !((uintptr_t)a.data % 8) && !((a.stride * sizeof(S)) % 8) && !(a.channels % V8);
+    if (variant < 0 || variant > 2)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
     if (variant == 0 && a16)
         return launch_il_v<P, KIND, M, V16, 8>(a, true, stream);
-    if (variant == 4 && a16) // 16-byte lanes, four rows in flight per wave (the default until U = 8 measured +2.6 points)
-        return launch_il_v<P, KIND, M, V16, 4>(a, true, stream);
     if constexpr (sizeof(S) == 4) {
-        if (variant == 3 || !a8)
+        if (variant == 2 || !a8)
             return launch_il_v<P, KIND, M, 1, 8>(a, true, stream);
     }
     if (a8)
-        return launch_il_v<P, KIND, M, V8, 8>(a, variant != 2, stream);
+        return launch_il_v<P, KIND, M, V8, 8>(a, true, stream);
     return fail(SDSP_HIP_ERR_INVALID_ARG, "interleaved layout needs 8-byte aligned rows");
 }
 template <typename P, int KIND> int launch_il_k(const iir_args &a, int variant, hipStream_t stream)
