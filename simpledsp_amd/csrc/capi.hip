@@ -400,8 +400,9 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.tw_1024 = p->tw1;
             a.sync = p->sync;
             a.count = std::min<uint64_t>(p->sync_count, batch - done);
-            a.ring = (uint32_t)kFft1mRing;
-            a.lag = 1;
+            // a ring of 4 with pass 2 two steps behind measured 42.0-42.2 %, 3 / one step 41.4-41.6 % (profiles/r02_fft1m_lab.md)
+            a.ring = p->ws_batch >= 4 * kFft1mQueues ? 4 : (uint32_t)kFft1mRing;
+            a.lag = a.ring - 2;
             a.queues = (uint32_t)kFft1mQueues;
             a.scale = scale;
             a.reverse = rev;

@@ -41,9 +41,12 @@ constexpr int kTile = 16;      // sequences per tile
 constexpr int kThreads = 512;  // 16 sequences x 32 threads
 constexpr int kTiles = 1024 / kTile;
 // dynamic LDS: one real plane [row][col] (64 KiB), W_1024 (8 KiB), the column part of the inter-pass twiddle (4 KiB),
-// the fused kernel's ticket mailbox (16 B)
+// the fused kernel's ticket mailbox (16 B), pass 2's thread twiddles [stage][lane] = W_1024^(lane << stage) (1.25 KiB:
+// gathering them from the W_1024 copy is a 2- to 16-way bank conflict, 7.8 % of the kernel's LDS cycles)
 constexpr size_t kPlaneBytes = 1024 * kTile * sizeof(float);
-constexpr size_t kLdsBytes = kPlaneBytes + 1024 * sizeof(float2) + 32 * kTile * sizeof(float2) + 16;
+constexpr size_t kMailOffset = kPlaneBytes + 1024 * sizeof(float2) + 32 * kTile * sizeof(float2);
+constexpr size_t kRowTwOffset = kMailOffset + 16;
+constexpr size_t kLdsBytes = kRowTwOffset + 5 * 32 * sizeof(float2);
 
 // Intermediate layouts.  ROWS: the [k1][n2] matrix itself (pass 1 writes 128-B segments 8 KiB apart, pass 2 reads
 // whole 8 KiB rows).  BLOCKED: [n2 / 16][k1][n2 % 16] -- a pass-1 tile's output is ONE contiguous 128 KiB block,
@@ -165,7 +168,7 @@ __device__ __forceinline__ void cols_tile(const float2 *in_x, float2 *ws_x, uint
 // ---- pass 2: 16 rows of one transform, written transposed ------------------------------------------
 template <bool REV, int MODE, int LAYOUT, bool NT_OUT>
 __device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *w1k,
-                                          float scale)
+                                          const float2 *wrow, float scale)
 {
     constexpr bool MATH = MODE == MODE_FFT;
     const uint32_t t = threadIdx.x;
@@ -193,7 +196,7 @@ __device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uin
     // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows
     const uint32_t rb = t & 15, ub = t >> 4;
     if constexpr (MATH) {
-        fft32_dif<REV, true>(x, w1k, ua);
+        fft32_dif<REV, true, 0, true>(x, wrow + ua, 32); // stage s: wrow[32 s + ua] = W_1024^(ua << s)
         // write slot ra*1024 + ((ua + 32k) ^ (ra | ((k&1) << 4))): the XOR touches the low 5 bits only
         //   -> bases (ua ^ ra) and (ua ^ ra ^ 16) + 32k;
         // read slot rb*1024 + ((32ub + k) ^ (rb | ((ub&1) << 4))) = rb*1024 + 32ub + (k ^ rb ^ 16(ub&1)):
@@ -254,6 +257,10 @@ __device__ __forceinline__ void rows_tile(const float2 *ws_x, float2 *out_x, uin
 __device__ __forceinline__ void stage_w1k(float2 *w1k, const float2 *tw_1024)
 {
     reinterpret_cast<float4 *>(w1k)[threadIdx.x] = reinterpret_cast<const float4 *>(tw_1024)[threadIdx.x];
+    if (threadIdx.x < 160) { // pass 2's thread twiddles, [stage][lane]
+        float2 *wrow = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(w1k) - kPlaneBytes + kRowTwOffset);
+        wrow[threadIdx.x] = tw_1024[(threadIdx.x & 31u) << (threadIdx.x >> 5)];
+    }
 }
 
 // ---- two launches per chunk (variant 1) ----------------------------------------------------------------
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_rows(const float2 *__r
     __syncthreads();
     const uint32_t tile = blockIdx.x % kTiles;
     const uint64_t xform = blockIdx.x / kTiles;
-    rows_tile<REV, MODE, LAYOUT, true>(ws + xform * (1ull << 20), out + xform * (1ull << 20), tile, plane, w1k, scale);
+    const float2 *wrow = reinterpret_cast<const float2 *>(sdsp_fft1m_smem + kRowTwOffset);
+    rows_tile<REV, MODE, LAYOUT, true>(ws + xform * (1ull << 20), out + xform * (1ull << 20), tile, plane, w1k, wrow, scale);
 }
 
 // ---- two passes of DIFFERENT chunks in one launch (software pipelining across launches) -----------------------------
@@ -318,7 +326,8 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_mixed(const float2 *in
     if (first)
         cols_tile<REV, MODE, LAYOUT, true>(in1 + xoff, ws1 + xoff, tile, plane, w1k, qtab);
     else
-        rows_tile<REV, MODE, LAYOUT, true>(ws2 + xoff, out2 + xoff, tile, plane, w1k, scale);
+        rows_tile<REV, MODE, LAYOUT, true>(ws2 + xoff, out2 + xoff, tile, plane, w1k,
+                                           reinterpret_cast<const float2 *>(sdsp_fft1m_smem + kRowTwOffset), scale);
 }
 
 // ---- one persistent launch per batch ----------------------------------------------------------------------
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
     // mailbox: [0], [1] the item's ticket, alternating per iteration -- an iteration without work has no barrier between
     // the other waves' read of its ticket and lane 0's write of the next one, so the next one goes to the other word;
     // [2] go / abort of the item's wait
-    unsigned *mail = reinterpret_cast<unsigned *>(qtab + 32 * kTile);
+    unsigned *mail = reinterpret_cast<unsigned *>(sdsp_fft1m_smem + kMailOffset);
 
     // flags & 4 (lab): bind the workgroup to the queue of the XCD it runs on (HW_REG_XCC_ID, bits 3:0) -- a transform's two
     // passes then run on ONE XCD and its intermediate is produced and consumed behind one L2
@@ -449,7 +458,8 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
         if (first)
             cols_tile<REV, MODE, LAYOUT, true>(data_x, ws_x, tile, plane, w1k, qtab);
         else
-            rows_tile<REV, MODE, LAYOUT, true>(ws_x, data_x, tile, plane, w1k, a.scale);
+            rows_tile<REV, MODE, LAYOUT, true>(ws_x, data_x, tile, plane, w1k,
+                                               reinterpret_cast<const float2 *>(sdsp_fft1m_smem + kRowTwOffset), a.scale);
 
         // ---- publish: pass 1 hands its output to other workgroups; pass 2 frees the ring slot, and its reads
         // of the slot must be complete (they are: the values were consumed) before the slot's next tenant stores

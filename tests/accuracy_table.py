@@ -21,9 +21,11 @@ def rel(got, ref):
 
 print("| kernel | case | max normwise error | bound |\n|---|---|---|---|")
 for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20):
-    for radix in (2, 4):
+    for radix in (2, 4, 0):
         if radix == 4 and not sd.isPowerOf4(n):
             continue
+        if radix == 0 and n != 8192:
+            continue  # AUTO: only at 8192 a kernel of its own (mixed radix)
         batch = max(2, min(64, (1 << 16) // n))
         x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
         errs = []
@@ -32,7 +34,7 @@ for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20):
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
             torch.cuda.synchronize()
-            errs.append(rel(d.cpu().numpy(), o.fft(x.astype(np.complex128), radix, rev)))
+            errs.append(rel(d.cpu().numpy(), o.fft(x.astype(np.complex128), radix or 2, rev)))
         print(f"| `{plan.info.kernel.decode()}` | N = {n}, radix {radix}, fwd / rev | {errs[0]:.2e} / {errs[1]:.2e} | 1e-6 |")
 
 # cascaded biquads, BASELINE config-4 filter, f32
@@ -49,6 +51,22 @@ for c in range(64):
     f.set_lp_coeff(10e3, 100e3)
     want.append(f.process(x[c].astype(np.float64)))
 print(f"| `sdsp_iir_supertile_kernel` | 4-section LP, 4096 samples, f32 | {rel(d.cpu().numpy(), np.array(want)):.2e} | 1e-6 (f64: bit-exact) |")
+
+# the same filter and a low cutoff (f0/fs = 0.005) in pure f32 and in the mixed mode (float samples, double recurrence)
+for f0 in (10e3, 500.0):
+    for prec, name in ((sd.F32, "f32"), (sd.F32_F64STATE, "float samples + double recurrence")):
+        bank = sd.casc_2o_iir(4, 64, prec, sd.IIR_GENERIC)
+        bank.set_lp_coeff(f0, 100e3)
+        d = torch.from_numpy(x).cuda()
+        bank.process(d)
+        torch.cuda.synchronize()
+        want = []
+        for c in range(64):
+            f = o.iir(4)
+            f.set_lp_coeff(f0, 100e3)
+            want.append(f.process(x[c].astype(np.float64)))
+        print(f"| `sdsp_iir_supertile_kernel` | 4-section LP f0/fs = {f0 / 100e3:g}, 4096 samples, {name} | {rel(d.cpu().numpy(), np.array(want)):.2e} | "
+              f"{'1e-6 (BASELINE filter only)' if prec == sd.F32 else '1.2e-7'} |")
 
 # FIR, f32
 for taps in (16, 32, 64):

@@ -12,9 +12,10 @@ run() {
     rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
     echo "$tag done"
 }
-run fft4096
+run fft4096 --no-other-configs
 run fft4096_r2 --workload fft --n 4096 --radix 2
 run fft8192 --workload fft --n 8192 --radix 2
+run fft8192_mix --workload fft --n 8192 --radix 0
 run fft16384 --workload fft --n 16384 --radix 2
 run fft1024 --workload fft --n 1024 --radix 2
 run fft1m --workload fft1m
