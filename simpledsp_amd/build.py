@@ -37,6 +37,7 @@ SOURCES = {
     "fft_big.hip": ["-fno-slp-vectorize"],
     "fft_mix.hip": ["-fno-slp-vectorize"],
     "fft_mid.hip": ["-fno-slp-vectorize"],
+    "fft_2pass.hip": ["-fno-slp-vectorize"],
     "iir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "fir.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],  # f64 taps: multiply then add, like the oracle
 }

@@ -412,8 +412,28 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return SDSP_HIP_OK;
     }
 
-    // N = 2^16 .. 2^19, f32: three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel
-    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == 0) {
+    // N = 2^16 .. 2^19, f32: two passes over HBM (fft_2pass.hip), in chunks whose intermediate is at most 256 MiB
+    if (p->path == PATH_FOUR_STEP && p->precision == SDSP_HIP_F32 && variant == 0 && fft_2pass_supports(p->n)) {
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 25) / p->n));
+        for (uint64_t done = 0; done < batch; done += chunk) {
+            fft_2pass_args a;
+            a.data = reinterpret_cast<char *>(data) + done * p->n * 8;
+            a.workspace = p->workspace;
+            a.tw_1024 = p->tw1024;
+            a.n = p->n;
+            a.count = std::min<uint64_t>(chunk, batch - done);
+            a.scale = (float)(1.0 / p->n);
+            a.reverse = rev;
+            if (int rc = launch_fft_2pass_f32(a, stream))
+                return rc;
+        }
+        return SDSP_HIP_OK;
+    }
+
+    // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel: f32 N = 2^21 .. 2^23, f64
+    // N = 2^14 .. 2^21, and variant 1 of the f32 sizes above
+    const bool two_pass_size = p->precision == SDSP_HIP_F32 && fft_2pass_supports(p->n);
+    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == (two_pass_size ? 1 : 0)) {
         const uint32_t n2 = p->n / 16;
         uint64_t done = 0;
         while (done < batch) {
@@ -885,7 +905,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
     const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 &&
                      p->variant == (mix_size ? 1 : 0) && !p->real_mode && fft_big_supports(p->n, p->radix);
-    const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == 0;
+    const bool two_pass = p->path == PATH_FOUR_STEP && p->precision == SDSP_HIP_F32 && fft_2pass_supports(p->n);
+    const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == (two_pass ? 1 : 0);
     info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
     if (mid) { // column step + the rows' own passes + untwist
         sdsp_hip_fft_plan_info rows;
@@ -909,6 +930,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = "sdsp_fft_mix_f32";
     if (mid)
         name = "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16";
+    if (two_pass && p->variant == 0)
+        name = "sdsp_fft2p_cols+sdsp_fft2p_rows";
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }

@@ -1,0 +1,280 @@
+// fft_2pass.hip -- batched N = 2^16 .. 2^19 complex f32 FFT in TWO passes over HBM, for gfx950: the tile scheme of the
+// N = 2^20 kernels (fft1m_kernels.h) generalised to N = N1 x N2 with N1, N2 in {256, 512, 1024}.
+//
+// Radix-2 butterfly stages of sdsp::fft_radix2 (fft.h:276-294) as a four-step decomposition, the transform viewed as a
+// row-major [n1][n2] matrix with N2 columns:
+//
+//   pass 1 (sdsp_fft2p_cols)  for 16 adjacent columns n2: log2 N1 radix-2 DIF stages over n1 (stride N2), times the
+//                             inter-pass twiddle W_N^(n2*k1), written to the intermediate [n2 / 16][k1][n2 % 16] (a tile's
+//                             output is one contiguous block of 128 * N1 bytes)
+//   pass 2 (sdsp_fft2p_rows)  for 16 adjacent rows k1: log2 N2 stages over n2, written transposed, X[k1 + N1*k2], back into
+//                             the caller's buffer (128-byte segments)
+//
+// Both passes: a sequence of length Ns = 32 T is held by T threads with 32 points each; the first register pass runs five DIF
+// stages across the thread's 32 points (row stride T), ONE exchange through LDS (plane by plane: real, then imaginary)
+// regroups them so that a thread holds 32 consecutive points, and the second register pass runs the remaining log2 T stages
+// on 32 / T independent groups of T points.  Stage twiddles W_Ns^(2^s u) come from an LDS copy of W_1024 (pass 1) or a
+// [stage][lane] table built from it (pass 2) times compile-time W_32 constants (fft32.h); the inter-pass twiddle is
+// W_1024^(m >> (L - 10)) from that table times a two-term series for the remaining angle (< 2 pi / 1024), as in fft1m.
+// LDS planes are XOR-swizzled: all reads conflict-free; pass 2's writes 2-way (N2 = 512) / 4-way (N2 = 256) on ds_write_b32.
+//
+// Replaces, for these sizes, the three streaming passes of fft_mid.hip (16-point column step, 16 x batch row transforms,
+// untwist): two passes over HBM instead of three.
+#include <hip/hip_runtime.h>
+
+#include "fft32.h"
+#include "sdsp_hip_internal.h"
+
+namespace sdsp_hip
+{
+namespace
+{
+using namespace fft32;
+
+constexpr int kTile = 16; // sequences per tile
+
+template <int BITS> __device__ __forceinline__ uint32_t brev_bits(uint32_t v) { return BITS == 0 ? 0u : (__brev(v) >> (32 - BITS)); }
+
+// W_N^m, N = 2^L, m < N: coarse factor from the LDS copy of W_1024, fine factor (angle < 2 pi / 1024) from two series terms
+template <int L, bool REV> __device__ __forceinline__ float2 twiddle_n(const float2 *w1k, uint32_t m)
+{
+    constexpr int FB = L - 10; // fine bits
+    const float th = (float)(m & ((1u << FB) - 1u)) * (6.283185307179586476925f / (float)(1u << L));
+    const float th2 = th * th;
+    const float sn = th - th * th2 * 0.16666667f;
+    const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
+    return cmul(w1k[m >> FB], fine);
+}
+
+// ---- pass 1: 16 columns of one transform; 16 * T1 threads ----------------------------------------------------
+// LDS: plane N1 x 16 floats, then W_1024 (8 KiB), then qtab 32 x 16 float2 (4 KiB)
+template <int L, int L1, bool REV>
+__global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const float2 *__restrict__ in, float2 *__restrict__ ws,
+                                                                          const float2 *__restrict__ tw_1024)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32, THREADS = kTile * T1, TILES = N2 / kTile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(float));
+    float2 *qtab = w1k + 1024;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < 512; i += THREADS)
+        reinterpret_cast<float4 *>(w1k)[i] = reinterpret_cast<const float4 *>(tw_1024)[i];
+    const uint32_t tile = blockIdx.x % TILES;
+    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+    const uint32_t c = t & 15, u = t >> 4; // u < T1
+    const uint32_t n2 = tile * kTile + c;
+
+    // rows u + T1 k of column n2
+    const float2 *src_tile = in + xoff + tile * kTile;
+    const uint32_t toff = (u * N2 + c) * 8u;
+    float2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = nt_load(at(src_tile + (size_t)T1 * N2 * k, toff));
+    __syncthreads(); // w1k staged
+
+    // the column part of the inter-pass twiddle: W_N^(n2 * j * 2^(L1-5)), j < 32; 32 / T1 entries per thread
+#pragma unroll
+    for (int i = 0; i < 32 / T1; i++) {
+        const uint32_t j = u + T1 * i;
+        qtab[j * 16 + c] = twiddle_n<L, REV>(w1k, (n2 * j) << (L1 - 5));
+    }
+    fft32_dif<REV, true>(x, w1k, u * (1024 / N1)); // W_N1^(u 2^s) = W_1024^((u 1024/N1) << s)
+
+    // exchange rows {u + T1 k} -> {32 u + k}; slot(row, col) = (row * 16 + col) ^ (((row >> 5) & 1) << 4)
+    {
+        float *const w0 = plane + (u * 16 + c);
+        float *const w1 = plane + ((u * 16 + c) ^ 16);
+        const int flip = (int)(u & 1) * 16;
+        const float *const r_even = plane + (512 * u + c) + flip;
+        const float *const r_odd = plane + (512 * u + c) - flip;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) // row u + T1 k: bit 5 of the row = bit of k (no carry from u < T1)
+                ((((k * T1) >> 5) & 1) ? w1 : w0)[16 * T1 * k] = half ? x[k].y : x[k].x;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const float f = ((k & 1) ? r_odd : r_even)[16 * k];
+                if (half)
+                    x[k].y = f;
+                else
+                    x[k].x = f;
+            }
+            if (half == 0)
+                __syncthreads();
+        }
+    }
+    fft32_dif<REV, false, 10 - L1>(x, w1k, 0); // the last log2 T1 stages on 32 / T1 groups of T1 consecutive rows
+
+    // row 32 u + k holds Y[k1], k1 = bit_reverse_L1(32 u + k) = (bit_reverse5(k) << (L1 - 5)) | bit_reverse(u)
+    const uint32_t bu = brev_bits<L1 - 5>(u);
+    const float2 pw = twiddle_n<L, REV>(w1k, n2 * bu);
+    const float2 *const qcol = qtab + c;
+    float2 *dst_tile = ws + xoff + (size_t)tile * (N1 * kTile); // [tile][k1][c]
+    const uint32_t soff = (bu * 16 + c) * 8u;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        const int j = (int)(__brev((uint32_t)k) >> 27);
+        *at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff) = cmul(x[k], cmul(pw, qcol[16 * j]));
+    }
+}
+
+// ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
+// LDS: plane 16 x N2 floats, then pass 2's thread twiddles [stage][lane] (5 x 32 float2)
+template <int L, int L1, bool REV>
+__global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const float2 *__restrict__ ws, float2 *__restrict__ out,
+                                                                              const float2 *__restrict__ tw_1024, float scale)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32, THREADS = kTile * T2, TILES = N1 / kTile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
+    float2 *wrow = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(float));
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < 5 * 32; i += THREADS) // [stage][lane] = W_N2^(lane << stage) = W_1024^((lane 1024/N2) << stage)
+        wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : float2{ 1.0f, 0.0f };
+    const uint32_t tile = blockIdx.x % TILES;
+    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+
+    // first register pass: T2 lanes run along a row; element n2 = ua + T2 k of row k1 = 16 tile + ra lives at
+    // [(n2 >> 4)][k1][n2 & 15] of the intermediate
+    const uint32_t ra = t / T2, ua = t % T2;
+    const float2 *src = ws + xoff + (size_t)tile * (kTile * kTile);
+    float2 x[32];
+    if constexpr (T2 == 32) {
+        const uint32_t aoff = ((ua >> 4) * (N1 * kTile) + ra * 16 + (ua & 15)) * 8u;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = *at(src + (size_t)2 * k * (N1 * kTile), aoff);
+    } else if constexpr (T2 == 16) {
+        const uint32_t aoff = (ra * 16 + ua) * 8u;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = *at(src + (size_t)k * (N1 * kTile), aoff);
+    } else {
+        static_assert(T2 == 8, "row length 256, 512 or 1024");
+        const uint32_t aoff = (ra * 16 + ua) * 8u;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = *at(src + (size_t)(k >> 1) * (N1 * kTile) + 8 * (k & 1), aoff);
+    }
+    __syncthreads(); // wrow staged
+    fft32_dif<REV, true, 0, true>(x, wrow + ua, 32);
+
+    // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows:
+    //   slot(row, pos) = row * N2 + (pos ^ (row | (((pos >> 5) & 1) << 4)))
+    // write pos = ua + T2 k of row ra; read pos = 32 ub + k of row rb
+    const uint32_t rb = t & 15, ub = t >> 4; // ub < T2
+    {
+        float *wb0, *wb1; // bases of the writes; the per-k part is a compile-time offset
+        if constexpr (T2 == 32) { // low 5 bits of pos = ua; bit 5 = k & 1
+            wb0 = plane + ra * N2 + (ua ^ ra);
+            wb1 = plane + ra * N2 + (ua ^ ra ^ 16);
+        } else if constexpr (T2 == 16) { // low 4 bits ua, bit 4 = k & 1, bit 5 = (k >> 1) & 1
+            wb0 = wb1 = plane + ra * N2 + (ua ^ ra);
+        } else { // low 3 bits ua, bit 3 = k & 1, bit 4 = (k >> 1) & 1, bit 5 = (k >> 2) & 1
+            wb0 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (ra >> 3);       // k even: bit 3 = 0 ^ (ra >> 3)
+            wb1 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (1 - (ra >> 3)); // k odd:  bit 3 = 1 ^ (ra >> 3)
+        }
+        const float *const r_base = plane + rb * N2 + 32 * ub;
+        const uint32_t rx = rb | ((ub & 1) << 4);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const float f = half ? x[k].y : x[k].x;
+                if constexpr (T2 == 32)
+                    ((k & 1) ? wb1 : wb0)[32 * k] = f;
+                else if constexpr (T2 == 16)
+                    wb0[16 * ((k ^ (k >> 1)) & 1) + 32 * (k >> 1)] = f;
+                else
+                    ((k & 1) ? wb1 : wb0)[16 * (((k >> 1) ^ (k >> 2)) & 1) + 32 * (k >> 2)] = f;
+            }
+            __syncthreads();
+            {
+                uint32_t q = rx;
+                asm volatile("" : "+v"(q)); // the 32 XOR'ed addresses are rebuilt, not kept in registers
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const float f = r_base[k ^ q];
+                    if (half)
+                        x[k].y = f;
+                    else
+                        x[k].x = f;
+                }
+            }
+            if (half == 0)
+                __syncthreads();
+        }
+    }
+    fft32_dif<REV, false, 10 - L2>(x, wrow, 0);
+
+    // position 32 ub + k of row k1 holds X[k1 + N1 k2], k2 = (bit_reverse5(k) << (L2 - 5)) | bit_reverse(ub): 16 lanes write
+    // 128 contiguous bytes (streaming store of the final result)
+    float2 *dst_tile = out + xoff + tile * kTile;
+    const uint32_t bub = brev_bits<L2 - 5>(ub);
+    const uint32_t boff = (bub * N1 + rb) * 8u;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if ((k & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        float2 v = x[k];
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            v.x *= scale;
+            v.y *= scale;
+        }
+        nt_store(at(dst_tile + (size_t)(__brev((uint32_t)k) >> 27) * ((size_t)N1 << (L2 - 5)), boff), v);
+    }
+}
+
+template <int L, int L1, bool REV> int launch_pair(const fft_2pass_args &a, hipStream_t s)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
+    constexpr size_t lds_cols = (size_t)N1 * kTile * 4 + 1024 * 8 + 32 * kTile * 8;
+    constexpr size_t lds_rows = (size_t)N2 * kTile * 4 + 5 * 32 * 8;
+    static std::atomic<uint64_t> done_c{ 0 }, done_r{ 0 };
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_cols<L, L1, REV>), lds_cols, done_c))
+        return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows<L, L1, REV>), lds_rows, done_r))
+        return rc;
+    const uint64_t blocks_c = a.count * (N2 / kTile), blocks_r = a.count * (N1 / kTile);
+    if (blocks_c > 0x7fffffffull || blocks_r > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
+    float2 *d = reinterpret_cast<float2 *>(a.data), *ws = reinterpret_cast<float2 *>(a.workspace);
+    const float2 *tw = reinterpret_cast<const float2 *>(a.tw_1024);
+    hipLaunchKernelGGL((sdsp_fft2p_cols<L, L1, REV>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
+    hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, a.scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+template <int L, int L1> int launch_dir(const fft_2pass_args &a, hipStream_t s)
+{
+    return a.reverse ? launch_pair<L, L1, true>(a, s) : launch_pair<L, L1, false>(a, s);
+}
+} // namespace
+
+bool fft_2pass_supports(uint32_t n) { return n >= (1u << 16) && n <= (1u << 19) && sdsp_hip_is_power_of_2(n); }
+
+// both passes over one chunk of `count` transforms (the workspace holds `count` intermediates)
+int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream)
+{
+    if (a.count == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (a.n) {
+    // N1 x N2: the longer factor goes to pass 2, whose exchange writes are conflict-free at N2 = 1024 only
+    case 1u << 16: return launch_dir<16, 8>(a, s);  //  256 x  256
+    case 1u << 17: return launch_dir<17, 8>(a, s);  //  256 x  512
+    case 1u << 18: return launch_dir<18, 9>(a, s);  //  512 x  512
+    case 1u << 19: return launch_dir<19, 9>(a, s);  //  512 x 1024
+    default: break;
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
+}
+} // namespace sdsp_hip

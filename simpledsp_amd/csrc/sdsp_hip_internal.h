@@ -109,7 +109,20 @@ struct fft_mix_args {
 bool fft_mix_supports(uint32_t n);
 int launch_fft_mix_f32(const fft_mix_args &a, void *stream);
 
-// N = 2^16 .. 2^19, f32: the two streaming passes around 16 x batch row transforms (fft_mid.hip)
+// N = 2^16 .. 2^19, f32: two passes over HBM, N = N1 x N2 with N1, N2 in {256, 512, 1024} (fft_2pass.hip)
+struct fft_2pass_args {
+    void *data;          // count x n complex, in place
+    void *workspace;     // count x n complex
+    const void *tw_1024; // W_1024^j, direction-folded
+    uint32_t n;
+    uint64_t count;
+    float scale;
+    int reverse;
+};
+bool fft_2pass_supports(uint32_t n);
+int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream);
+
+// N = 2^16 .. 2^19, f32 (variant 1) and larger / f64: the two streaming passes around 16 x batch row transforms (fft_mid.hip)
 int launch_fft_mid_cols(int precision, const void *in, void *out, const void *tw, uint32_t n2, uint64_t batch, int reverse,
                         void *stream);
 int launch_fft_mid_untwist(int precision, const void *in, void *out, uint32_t n2, uint64_t batch, void *stream);

@@ -257,30 +257,30 @@ def test_fft4096_ragged_batches_all_variants(sd, torch_cuda, oracle, batch):
 @pytest.mark.parametrize("n,radix,batch", [(1 << 16, 2, 5), (1 << 16, 4, 3), (1 << 17, 2, 3), (1 << 18, 4, 2), (1 << 19, 2, 2),
                                            (1 << 21, 2, 2), (1 << 22, 4, 1)])  # > 2^20: nested (the rows are three-pass plans)
 def test_three_pass_mid_sizes(sd, torch_cuda, oracle, n, radix, batch):
-    """N = 2^16 .. 2^19, f32 (csrc/fft_mid.hip): 16-point column step, 16 x batch rows on the tuned
-    single-pass kernels, untwist.  Against the oracle, against the general four-step (variant 1), and with a
-    plan whose workspace is smaller than the batch (slices)."""
+    """N = 2^16 .. 2^19, f32: two passes over HBM (csrc/fft_2pass.hip, N = N1 x N2 with N1, N2 in {256, 512, 1024});
+    variant 1: the three streaming passes of csrc/fft_mid.hip (16-point column step, 16 x batch rows on the tuned
+    single-pass kernels, untwist) -- which N = 2^21 .. 2^23 still run, nested; last variant: the general four-step
+    through the coverage kernel.  All against the oracle, with a plan whose workspace is smaller than the batch (slices)."""
     torch = torch_cuda
     rng = np.random.default_rng(n + radix + batch)
     x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    two_pass = n < (1 << 20)
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=2)  # batch > max_batch: the exec runs in slices
-        assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
-        assert plan.info.hbm_passes == (3 if n < (1 << 20) else 5)  # nested: column step + three-pass rows + untwist
-        d = torch.from_numpy(x).cuda()
-        guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
-        plan.exec(d)
-        torch.cuda.synchronize()
-        got = d.cpu().numpy()
-        assert bool((guard == 7.0 + 3.0j).all())
-        assert rel_max_err(got, want) < TOL32, (n, radix, rev, rel_max_err(got, want))
-        plan.set_variant(1)
-        assert plan.info.hbm_passes == 2
-        d2 = torch.from_numpy(x).cuda()
-        plan.exec(d2)
-        torch.cuda.synchronize()
-        assert rel_max_err(d2.cpu().numpy(), want) < TOL32
+        expect = [("sdsp_fft2p_cols", 2), ("sdsp_fft_col16_kernel", 3), ("sdsp_fft_tile_kernel", 2)] if two_pass else \
+                 [("sdsp_fft_col16_kernel", 4), ("sdsp_fft_tile_kernel", 2)]  # nested: column step + two-pass rows + untwist
+        for variant, (kernel, passes) in enumerate(expect):
+            plan.set_variant(variant)
+            assert plan.info.kernel.decode().startswith(kernel), (variant, plan.info.kernel)
+            assert plan.info.hbm_passes == passes
+            d = torch.from_numpy(x).cuda()
+            guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
+            plan.exec(d)
+            torch.cuda.synchronize()
+            got = d.cpu().numpy()
+            assert bool((guard == 7.0 + 3.0j).all())
+            assert rel_max_err(got, want) < TOL32, (n, radix, rev, variant, rel_max_err(got, want))
 
 
 @pytest.mark.parametrize("n,radix,batch", [(1 << 14, 2, 5), (1 << 14, 4, 3), (1 << 15, 2, 3), (1 << 16, 4, 2), (1 << 18, 2, 2)])
