@@ -196,7 +196,7 @@ public:
     }
     // fast convolution: data <- IFFT(FFT(data) .* h) per transform, in place; needs a
     // FORWARD plan; device pointers; h = n complex values (frequency response, natural order).
-    // One fused kernel at n = 4096 / radix 4 / float.
+    // One fused kernel for float n = 16 .. 16384 and double n = 16 .. 8192; three launches beyond.
     void convolve(std::complex<real_t> *device_data, const std::complex<real_t> *device_h, std::uint64_t batch,
                   void *stream = nullptr)
     {
@@ -210,29 +210,32 @@ private:
     std::unique_ptr<detail::fft_plan_handle> m_h;
 };
 
-// real-input packing: n_real float samples <-> packed half spectrum (n_real/2 complex,
-// element 0 = (X[0], X[n_real/2])), in place, half the bytes of the complex transform.
-class rfft_plan {
+// real-input packing: n_real real samples <-> packed half spectrum (n_real/2 complex,
+// element 0 = (X[0], X[n_real/2])), in place, half the bytes of the complex transform.  real_t = float
+// (n_real = 32 .. 32768) or double (32 .. 16384: the reference's precision).
+template <typename real_t> class rfft_plan_t {
 public:
-    rfft_plan(std::uint32_t n_real, int radix = 2, int direction = SDSP_HIP_FORWARD, std::uint64_t max_batch = 1, int device = 0)
+    rfft_plan_t(std::uint32_t n_real, int radix = 2, int direction = SDSP_HIP_FORWARD, std::uint64_t max_batch = 1, int device = 0)
         : m_n_real(n_real)
     {
-        detail::check(sdsp_hip_rfft_plan_create(&m_plan, n_real, radix, direction, max_batch, device));
+        detail::check(sdsp_hip_rfft_plan_create_p(&m_plan, n_real, radix, direction, detail::precision_of<real_t>::value,
+                                                  max_batch, device));
     }
-    ~rfft_plan() { sdsp_hip_fft_plan_destroy(m_plan); }
-    rfft_plan(const rfft_plan &) = delete;
-    rfft_plan &operator=(const rfft_plan &) = delete;
+    ~rfft_plan_t() { sdsp_hip_fft_plan_destroy(m_plan); }
+    rfft_plan_t(const rfft_plan_t &) = delete;
+    rfft_plan_t &operator=(const rfft_plan_t &) = delete;
     std::uint32_t size() const noexcept { return m_n_real; }
-    void exec(float *device_data, std::uint64_t batch, void *stream = nullptr)
+    void exec(real_t *device_data, std::uint64_t batch, void *stream = nullptr)
     {
         detail::check(sdsp_hip_fft_exec(m_plan, device_data, batch, stream));
     }
-    void exec_host(float *host_data, std::uint64_t batch) { detail::check(sdsp_hip_fft_exec_host(m_plan, host_data, batch)); }
+    void exec_host(real_t *host_data, std::uint64_t batch) { detail::check(sdsp_hip_fft_exec_host(m_plan, host_data, batch)); }
 
 private:
     std::uint32_t m_n_real;
     sdsp_hip_fft_plan *m_plan{ nullptr };
 };
+using rfft_plan = rfft_plan_t<float>;
 
 // batch of `batch` transforms of length n in host memory, in place
 template <class T = forward_fft, typename real_t> void fft_batch(int radix, std::complex<real_t> *data, std::uint32_t n, std::uint64_t batch)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "sdsp_hip_calc_twiddles": (_i, [C.c_uint, _i, _vp]),
     "sdsp_hip_fft_plan_create": (_i, [_pp, _u32, _i, _i, _i, _u64, _i]),
     "sdsp_hip_rfft_plan_create": (_i, [_pp, _u32, _i, _i, _u64, _i]),
+    "sdsp_hip_rfft_plan_create_p": (_i, [_pp, _u32, _i, _i, _i, _u64, _i]),
     "sdsp_hip_fft_plan_destroy": (_i, [_vp]),
     "sdsp_hip_fft_exec": (_i, [_vp, _vp, _u64, _vp]),
     "sdsp_hip_fft_exec_host": (_i, [_vp, _vp, _u64]),

@@ -320,6 +320,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.scale_d = 1.0 / p->n;
         a.reverse = rev;
         a.nontemporal = 1;
+        a.real_mode = p->real_mode;
+        a.tw2 = p->tw2;
         return launch_fft_reg_f64(a, stream);
     }
 
@@ -709,35 +711,43 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     return SDSP_HIP_OK;
 }
 
-int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **out, uint32_t n_real, int radix, int direction, uint64_t max_batch,
-                              int device)
+int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int radix, int direction, int precision,
+                                uint64_t max_batch, int device)
 {
     if (!out)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "plan out-pointer is null");
     *out = nullptr;
     if (!sdsp_hip_is_power_of_2(n_real) || n_real < 32)
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2! (real-input plans: >= 32)");
+    if (precision != SDSP_HIP_F32 && precision != SDSP_HIP_F64)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "precision must be SDSP_HIP_F32 or SDSP_HIP_F64");
     const uint32_t n = n_real / 2;
     if (radix == 4 && !sdsp_hip_is_power_of_4(n))
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT radix 4 size must be a power of 4! (n_real / 2)");
     if (radix != 2 && radix != 4)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix must be 2 or 4");
-    if (!fft_reg_supports(n, radix))
-        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768");
+    if (precision == SDSP_HIP_F32 ? !fft_reg_supports(n, radix) : !fft_reg64_supports(n, radix))
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768 (f32) / 32 .. 16384 (f64)");
     sdsp_hip_fft_plan *p = nullptr;
-    if (int rc = sdsp_hip_fft_plan_create(&p, n, radix, direction, SDSP_HIP_F32, max_batch, device))
+    if (int rc = sdsp_hip_fft_plan_create(&p, n, radix, direction, precision, max_batch, device))
         return rc;
-    p->path = PATH_REG; // also at n = 4096 (the tuned complex kernels have no split stage)
+    p->path = PATH_REG; // also at n = 4096 f32 (the tuned complex kernels have no split stage)
     p->real_mode = direction == SDSP_HIP_FORWARD ? 1 : 2;
     std::vector<double> w;
     make_twiddles(n_real, direction, w);
-    if (int rc = upload_twiddles(w, SDSP_HIP_F32, &p->tw2)) {
+    if (int rc = upload_twiddles(w, precision, &p->tw2)) {
         sdsp_hip_fft_plan_destroy(p);
         return rc;
     }
-    p->twiddle_bytes += (uint64_t)n_real * 8;
+    p->twiddle_bytes += (uint64_t)n_real * esize(precision);
     *out = p;
     return SDSP_HIP_OK;
+}
+
+int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **out, uint32_t n_real, int radix, int direction, uint64_t max_batch,
+                              int device)
+{
+    return sdsp_hip_rfft_plan_create_p(out, n_real, radix, direction, SDSP_HIP_F32, max_batch, device);
 }
 
 int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
@@ -876,6 +886,21 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
         a.real_mode = 3; // fused convolution: one kernel, h travels in tw2
         a.tw2 = h;
         return launch_fft_reg_f32(a, stream);
+    }
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0 && !p->real_mode) { // f64, N = 16 .. 8192
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->twt_reg;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = 1.0f;
+        a.scale_d = 1.0 / p->n;
+        a.reverse = 0;
+        a.nontemporal = 1;
+        a.real_mode = 3;
+        a.tw2 = h;
+        return launch_fft_reg_f64(a, stream);
     }
     if (!p->partner) {
         if (int rc = sdsp_hip_fft_plan_create(&p->partner, p->n, p->radix, SDSP_HIP_REVERSE, p->precision,

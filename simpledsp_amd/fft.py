@@ -163,11 +163,11 @@ class RfftPlan:
     forward_fft: float32 (..., n_real) -> the same memory viewed as complex64 (..., n_real/2) with
     out[..., k] = X[k] (0 < k < n_real/2) and out[..., 0] = X[0] + 1j*X[n_real/2]; reverse_fft inverts."""
 
-    def __init__(self, n_real: int, radix: int = 2, T=forward_fft, max_batch: int = 1, device: int = 0):
+    def __init__(self, n_real: int, radix: int = 2, T=forward_fft, max_batch: int = 1, device: int = 0, precision: int = L.F32):
         self._lib = L.load()
         self._h = C.c_void_p()
-        L.check(self._lib.sdsp_hip_rfft_plan_create(C.byref(self._h), n_real, radix, T.direction, max_batch, device))
-        self.n_real, self.radix, self.direction, self.device = n_real, radix, T.direction, device
+        L.check(self._lib.sdsp_hip_rfft_plan_create_p(C.byref(self._h), n_real, radix, T.direction, precision, max_batch, device))
+        self.n_real, self.radix, self.direction, self.device, self.precision = n_real, radix, T.direction, device, precision
 
     def close(self):
         if getattr(self, "_h", None):
@@ -180,8 +180,9 @@ class RfftPlan:
         """x: contiguous float32 device tensor (..., n_real), transformed in place; returns the complex
         view (forward) or x itself (reverse: pass the float32 view of the packed spectrum)."""
         import torch
-        if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.n_real:
-            raise ValueError("exec needs a contiguous float32 device tensor (..., n_real)")
+        want = torch.float64 if self.precision == L.F64 else torch.float32
+        if x.dtype != want or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.n_real:
+            raise ValueError("exec needs a contiguous device tensor (..., n_real) of the plan's real dtype")
         if x.device.index != self.device:
             raise ValueError("tensor lives on a different device than the plan")
         stream = torch.cuda.current_stream(x.device).cuda_stream
