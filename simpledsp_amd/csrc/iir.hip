@@ -18,6 +18,8 @@
 // current tile is computed.  Coefficients live in SGPRs (kernel arguments).
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
@@ -191,103 +193,6 @@ __global__ __launch_bounds__(256) void sdsp_iir_direct_kernel(iir_dev_args<typen
     store_state<R, M>(p, c, y1, y2, y3);
 }
 
-// ---- tiled variant.  ROWB = bytes of one channel covered per tile (T = ROWB / sizeof(R) samples).
-// Requirements (checked by the host): data 16-byte aligned, stride and samples multiples of 16 B.
-template <typename P, int KIND, int M, int ROWB, bool NT>
-__global__ __launch_bounds__(256) void sdsp_iir_tiled_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
-{
-    using S = typename P::S;
-    using R = typename P::R;
-    using V = typename vec16<S>::type;
-    constexpr int EPV = vec16<S>::n;             // elements per 16-byte vector
-    constexpr int T = ROWB / (int)sizeof(S);      // samples per tile row
-    constexpr int NV = ROWB / 16;                 // vectors per row == lanes per row
-    constexpr int RPI = 64 / NV;                  // rows covered by one wave-wide access
-    constexpr int PITCH = ROWB + 16;              // LDS row pitch in bytes (one vector of padding)
-    constexpr int WAVE_LDS = 64 * PITCH;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    unsigned char *tile = sdsp_iir_smem + wave * WAVE_LDS;
-
-    const uint64_t ch0 = ((uint64_t)blockIdx.x * 4 + wave) * 64;
-    const uint64_t my_ch = ch0 + lane;
-    const bool have_ch = my_ch < p.channels;
-
-    R y1[M + 1], y2[M + 1], y3[M + 1];
-    load_state<R, M>(p, have_ch ? my_ch : 0, y1, y2, y3);
-
-    // cooperative access pattern: vector `piece` of row `i * RPI + sub`
-    const int piece = lane % NV;
-    const int sub = lane / NV;
-    const uint64_t n_tiles = (p.samples + T - 1) / T;
-
-    V stage[NV]; // NV == number of wave-wide accesses per tile (64 rows / RPI rows each)
-    auto issue_loads = [&](uint64_t t) {
-        const uint64_t s0 = t * T + (uint64_t)piece * EPV;
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
-            stage[i] = V{};
-            if (ch < p.channels && s0 < p.samples)
-                stage[i] = gload16<S, NT>(p.data + ch * p.stride + s0);
-        }
-    };
-
-    if (n_tiles)
-        issue_loads(0);
-    for (uint64_t t = 0; t < n_tiles; t++) {
-        // staged registers -> LDS tile
-#pragma unroll
-        for (int i = 0; i < NV; i++)
-            *reinterpret_cast<V *>(tile + (i * RPI + sub) * PITCH + piece * 16) = stage[i];
-        __syncthreads();
-        if (t + 1 < n_tiles)
-            issue_loads(t + 1); // in flight while this tile is filtered
-
-        // every lane filters its own channel's T samples
-        const uint64_t left = p.samples - t * T;
-        const int valid = left < (uint64_t)T ? (int)left : T;
-        V *myrow = reinterpret_cast<V *>(tile + lane * PITCH);
-        if (valid == T) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                V x = myrow[v];
-                S *xe = reinterpret_cast<S *>(&x);
-#pragma unroll
-                for (int e = 0; e < EPV; e++)
-                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
-                myrow[v] = x;
-            }
-        } else {
-            for (int v = 0; v * EPV < valid; v++) { // samples is a multiple of EPV
-                V x = myrow[v];
-                S *xe = reinterpret_cast<S *>(&x);
-#pragma unroll
-                for (int e = 0; e < EPV; e++)
-                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
-                myrow[v] = x;
-            }
-        }
-        __syncthreads();
-
-        // LDS tile -> HBM with the cooperative pattern
-        const uint64_t s0 = t * T + (uint64_t)piece * EPV;
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const uint64_t ch = ch0 + (uint64_t)(i * RPI + sub);
-            if (ch < p.channels && s0 < p.samples) {
-                const V v = *reinterpret_cast<const V *>(tile + (i * RPI + sub) * PITCH + piece * 16);
-                gstore16<S, NT>(p.data + ch * p.stride + s0, v);
-            }
-        }
-        __syncthreads();
-    }
-    if (have_ch && p.samples)
-        store_state<R, M>(p, my_ch, y1, y2, y3);
-}
-
 // ---- super-tile variant (default).  One wave per workgroup owns 64 channels.  Per step it moves a
 // [64 channels x 512 bytes] super-tile: 32 sixteen-byte accesses per lane, issued ROW-GROUP-MAJOR --
 // the four consecutive 128-byte pieces of the same 8 channels in four back-to-back instructions -- so
@@ -408,6 +313,83 @@ __global__ __launch_bounds__(64) void sdsp_iir_supertile_kernel(iir_dev_args<typ
         }
     }
     if (have_ch && p.samples)
+        store_state<R, M>(p, my_ch, y1, y2, y3);
+}
+
+// ---- wide super-tile variant.  The same [64 channels x 512 bytes] super-tile in 128 VGPRs, but every load / store
+// instruction covers 512 CONTIGUOUS bytes of two channels (lanes 0-31 one row, lanes 32-63 the next) instead of 128 bytes of
+// eight: as a bare in-place copy that shape streams at 5.98 TB/s where four back-to-back 128-byte pieces stop at 5.66
+// (tools/membench.hip, round 1) -- and 5.66 is what the kernel above reaches.  The price is in the LDS transpose: a row's
+// 512 bytes are spread over 32 lanes, so the super-tile passes through LDS in two halves of 256 bytes per channel (17 KiB
+// per wave), each half written and read back by the half of the lanes that holds it (exec-masked ds_write/read_b128).
+template <typename P, int KIND, int M, bool NT>
+__global__ __launch_bounds__(64) void sdsp_iir_wide_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
+{
+    // whole super-tiles only: channels a multiple of 64, samples a multiple of 512 bytes (the launcher sends every other
+    // shape to the kernel above -- predicated edge paths in here cost 70 more registers and the second wave per SIMD)
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = typename vec16<S>::type;
+    constexpr int EPV = vec16<S>::n;
+    constexpr int ROWB = 512, HALFB = 256;
+    constexpr int T = ROWB / (int)sizeof(S); // samples per super-tile
+    constexpr int NVH = HALFB / 16;          // vectors per half row
+    constexpr int PITCH = HALFB + 16;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
+    unsigned char *tile = sdsp_iir_smem;
+    const int lane = threadIdx.x;
+    const uint64_t ch0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t my_ch = ch0 + lane;
+
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, my_ch, y1, y2, y3);
+
+    const int rsel = lane >> 5, col = lane & 31; // row of the pair, 16-byte column of the 512-byte segment
+    const int hsel = col >> 4;                   // which LDS pass holds this lane's column
+    unsigned char *const xchg = tile + rsel * PITCH + (col & 15) * 16;
+    // addresses = uniform base of the row pair (SGPRs) + ONE 32-bit per-lane byte offset (the global_load "saddr" form)
+    const uint32_t lane_off = (uint32_t)((rsel * p.stride + (uint64_t)col * EPV) * sizeof(S)); // the host checks the range
+    const uint64_t pair_step = 2 * p.stride; // elements between row pairs
+    auto at_lane = [&](S *uniform_base) { return reinterpret_cast<S *>(reinterpret_cast<char *>(uniform_base) + lane_off); };
+    const uint64_t n_super = p.samples / T;
+    for (uint64_t st = 0; st < n_super; st++) {
+        V stage[32]; // register i: rows 2i, 2i+1
+        S *const tile_base = p.data + ch0 * p.stride + st * T; // uniform
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            stage[i] = gload16<S, NT>(at_lane(tile_base + i * pair_step));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (hsel == h) {
+#pragma unroll
+                for (int i = 0; i < 32; i++)
+                    *reinterpret_cast<V *>(xchg + 2 * i * PITCH) = stage[i];
+            }
+            __syncthreads();
+            V *myrow = reinterpret_cast<V *>(tile + lane * PITCH);
+#pragma unroll
+            for (int v = 0; v < NVH; v++) {
+                V x = myrow[v];
+                S *xe = reinterpret_cast<S *>(&x);
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
+                myrow[v] = x;
+            }
+            __syncthreads();
+            if (hsel == h) {
+#pragma unroll
+                for (int i = 0; i < 32; i++)
+                    stage[i] = *reinterpret_cast<const V *>(xchg + 2 * i * PITCH);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            gstore16<S, NT>(at_lane(tile_base + i * pair_step), stage[i]);
+    }
+    if (p.samples)
         store_state<R, M>(p, my_ch, y1, y2, y3);
 }
 
@@ -543,11 +525,14 @@ template <typename P, int KIND, int M> int launch_km(const iir_args &a, int vari
     const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) &&
                          ((a.samples * sizeof(S)) % 16 == 0);
     // variants (identical arithmetic, bit-identical results):
-    //   0 super-tile, streaming accesses (default)   1 tiled, 128-byte rows, four waves per workgroup   2 direct (any alignment)
+    //   0 super-tile, streaming accesses (default)   1 wide super-tile (512 contiguous bytes per instruction)   2 direct
     // Measured and dropped (round 1, BASELINE config 4, f32): super-tile with the default cache policy 66 % (0: 70 %), of 3 / 2
-    // sub-tiles (384- / 256-byte bursts) 61.9 / 58.8 %, tiled with 256-byte rows 56 %.
+    // sub-tiles (384- / 256-byte bursts) 61.9 / 58.8 %, four-wave tiles with 128- / 256-byte rows 61 / 56 %.
     if (variant != 2 && !aligned)
         variant = 2; // shapes the vector kernels cannot address fall to the direct kernel
+    // the wide kernel takes whole super-tiles only; every other shape runs the super-tile kernel (identical arithmetic)
+    if (variant == 1 && (a.channels % 64 != 0 || (a.samples * sizeof(S)) % 512 != 0 || (a.stride + 128) * sizeof(S) >= (1ull << 32)))
+        variant = 0;
     if (variant == 2) {
         const uint64_t blocks = (a.channels + 255) / 256;
         hipLaunchKernelGGL((sdsp_iir_direct_kernel<P, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
@@ -558,10 +543,11 @@ template <typename P, int KIND, int M> int launch_km(const iir_args &a, int vari
         const size_t lds = 64 * (128 + 16);
         hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
     } else if (variant == 1) {
-        const uint64_t blocks = (a.channels + 255) / 256;
-        constexpr int ROWB = 128;
-        const size_t lds = 4 * 64 * (ROWB + 16);
-        hipLaunchKernelGGL((sdsp_iir_tiled_kernel<P, KIND, M, ROWB, true>), dim3((uint32_t)blocks), dim3(256), lds, stream, p);
+        const uint64_t blocks = (a.channels + 63) / 64;
+        if (blocks > 0x7fffffffull)
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+        const size_t lds = 64 * (256 + 16);
+        hipLaunchKernelGGL((sdsp_iir_wide_kernel<P, KIND, M, true>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
     } else {
         return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
     }

@@ -210,6 +210,30 @@ def test_mixed_precision_random_input_and_variants(sd, torch_cuda, oracle):
             assert rel_max_err(f32[7], want) > 20 * rel_max_err(outs[0][7], want)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64", "mixed"])
+def test_wide_supertile_kernel_is_bit_identical(sd, torch_cuda, precision):
+    """variant 1 (csrc/iir.hip: sdsp_iir_wide_kernel -- 512 contiguous bytes of two channels per load / store instruction)
+    takes whole super-tiles only (channels a multiple of 64, 512-byte multiples of samples); same arithmetic as variant 0,
+    so the same bits, also across calls (per-channel state) and for every kind."""
+    torch = torch_cuda
+    prec = {"f32": sd.F32, "f64": sd.F64, "mixed": sd.F32_F64STATE}[precision]
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((192, 1024)).astype(np.float64 if precision == "f64" else np.float32)
+    for nm, ftype in KINDS.items():
+        for kind in (sd.IIR_GENERIC, ftype):
+            outs = []
+            for variant in (0, 1):
+                bank = _bank(sd, 4, 192, prec, kind, ftype, 10e3, 100e3, 1.1, variant=variant)
+                d = torch.from_numpy(x.copy()).cuda()
+                bank.process(d, samples=512, offset=0)    # whole super-tiles: the wide kernel runs
+                bank.process(d, samples=384, offset=512)  # f32: 1536 bytes, f64: 3072 bytes -- still whole super-tiles
+                bank.process(d, samples=128, offset=896)
+                torch.cuda.synchronize()
+                outs.append((d.cpu().numpy(), bank.state.cpu().numpy()))
+            assert np.array_equal(outs[0][0], outs[1][0]), (precision, nm, kind)
+            assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_f32_specialised_kinds_and_streaming(sd, torch_cuda, oracle):
     rng = np.random.default_rng(11)
     x = rng.standard_normal((130, 2048)).astype(np.float32)
