@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import simpledsp_amd as sd
 
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 2, 4, 5]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2]
 chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 batch = 65536
 dev = torch.device("cuda:0")
