@@ -157,6 +157,12 @@ int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int rad
 int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction, int precision,
                                 uint64_t max_batch, int device);
 
+/* Synchronises the plan's device and reports the health of its last launch.  The persistent N = 2^20 kernel hands an
+ * intermediate from one workgroup to another inside a launch; every wait of that hand-off is bounded (2 s), and a wait that
+ * gives up marks the launch instead of hanging the GPU: this returns SDSP_HIP_ERR_HIP then, SDSP_HIP_OK otherwise (always OK
+ * for plans whose kernels have no in-kernel hand-off).  Has no reference counterpart. */
+int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
+
 typedef struct {
     uint32_t n;
     int radix;
@@ -172,7 +178,11 @@ typedef struct {
 int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *plan, sdsp_hip_fft_plan_info *info);
 /* copy the plan's resident twiddle row W_n^j (plan precision, n complex) back to the host */
 int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out);
-/* choose among kernel variants of a plan (tuning/testing); variant 0 is the default */
+/* choose among kernel variants of a plan (tuning/testing).  Variant 0 is the default; a plan has at most two documented
+ * alternates (same transform, same tolerance; DESIGN.md section 5 lists them per size: e.g. n = 4096 radix 4: 1, 2 = other
+ * store / barrier schedules of the same kernel; n = 8192 / 16384 mixed-radix plans: 1 = the radix-2-stage kernel; n = 2^16 ..
+ * 2^19: 1 = three streaming passes; n = 2^20: 1 = two launches per chunk); any larger number selects the untuned coverage
+ * kernel (fft_tile.hip), which the tests use as an independent implementation. */
 int sdsp_hip_fft_plan_set_variant(sdsp_hip_fft_plan *plan, int variant);
 
 /* ------------------------------------------------------------------ cascaded biquads */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sdsp_hip_fft_plan_get_info": (_i, [_vp, C.POINTER(PlanInfo)]),
     "sdsp_hip_fft_plan_get_twiddles": (_i, [_vp, _vp]),
     "sdsp_hip_fft_plan_set_variant": (_i, [_vp, _i]),
+    "sdsp_hip_fft_plan_status": (_i, [_vp]),
     "sdsp_hip_iir_design_lp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_hp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_bp": (_i, [_u32, _d, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),

@@ -961,6 +961,22 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     return SDSP_HIP_OK;
 }
 
+int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *p)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    if (int rc = use_device(p->device))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->path == PATH_FFT1M && p->sync) { // the persistent kernel's abort word (zeroed in front of every launch)
+        unsigned flag = 0;
+        HIP_TRY(hipMemcpy(&flag, reinterpret_cast<unsigned *>(p->sync) + 32 * kFft1mQueues, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag)
+            return fail(SDSP_HIP_ERR_HIP, "the last N = 2^20 launch gave up on a bounded wait between its two passes: its output is invalid");
+    }
+    return SDSP_HIP_OK;
+}
+
 int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *p, void *host_out)
 {
     if (!p || !host_out)

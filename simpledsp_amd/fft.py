@@ -108,6 +108,10 @@ class FftPlan:
     def set_variant(self, v: int):
         L.check(self._lib.sdsp_hip_fft_plan_set_variant(self._h, v))
 
+    def status(self):
+        """synchronise and raise if the plan's last launch gave up on a bounded in-kernel wait (N = 2^20 persistent kernel)"""
+        L.check(self._lib.sdsp_hip_fft_plan_status(self._h))
+
     @property
     def info(self) -> L.PlanInfo:
         info = L.PlanInfo()
