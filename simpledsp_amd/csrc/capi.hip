@@ -686,6 +686,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
             hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues));
+            if (e == hipSuccess) // the abort word must read 0 before the first persistent launch (sdsp_hip_fft_plan_status)
+                e = hipMemset(p->sync, 0, fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues));
             if (e != hipSuccess)
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft1m counters hipMalloc: ") + hipGetErrorString(e));
         }
