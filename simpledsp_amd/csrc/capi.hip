@@ -155,7 +155,7 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
 constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 // Tables of fft_mix.hip (N = R x 4096, R = 2 / 4): the N = 4096 radix-4 thread-twiddle table built from W_4096^j = W_N^(R j),
-// and the leading stage's thread twiddles [q - 1][t] = W_N^(q t), q < R, t < 256.
+// and the leading stage's thread twiddles [q - 1][t] = W_N^(q t), q < R, t < 256 (R = 2) / 512 (R = 4).
 int upload_thread_twiddles_mix(const std::vector<double> &w, uint32_t n, void **sub, void **lead)
 {
     const uint32_t R = n / 4096;
@@ -167,8 +167,9 @@ int upload_thread_twiddles_mix(const std::vector<double> &w, uint32_t n, void **
     if (int rc = upload_thread_twiddles_4096(w4096, 4, sub))
         return rc;
     std::vector<float> tab;
+    const uint32_t threads = R == 4 ? 512 : 256; // the N = 16384 kernel runs 512 threads per transform
     for (uint32_t q = 1; q < R; q++)
-        for (uint32_t t = 0; t < 256; t++) {
+        for (uint32_t t = 0; t < threads; t++) {
             tab.push_back((float)w[2 * (size_t)(q * t)]);
             tab.push_back((float)w[2 * (size_t)(q * t) + 1]);
         }

@@ -64,6 +64,21 @@ __device__ __forceinline__ void lead_stage(float2 (&x)[R][16], const float2 (&ws
     (lead_one<R, REV, Ks>(x, ws), ...);
 }
 
+// the leading radix-4 stage of the 512-thread form: y[r][j] = x[t + 512 (j + 8 r)] -> y_q[t + 512 j]; the twiddle W_N^(q n),
+// n = t + 512 j, is ws[q - 1] = W_N^(q t) times the constant W_32^(q j) = W_64^(2 q j)
+template <bool REV, int J> __device__ __forceinline__ void lead_one512(float2 (&y)[4][8], const float2 (&ws)[3])
+{
+    bfly4<REV>(y[0][J], y[1][J], y[2][J], y[3][J]);
+    y[1][J] = cmul(mul_w64<REV, 2 * J>(y[1][J]), ws[0]);
+    y[2][J] = cmul(mul_w64<REV, 4 * J>(y[2][J]), ws[1]);
+    y[3][J] = cmul(mul_w64<REV, 6 * J>(y[3][J]), ws[2]);
+}
+template <bool REV, int... Js>
+__device__ __forceinline__ void lead_stage512(float2 (&y)[4][8], const float2 (&ws)[3], std::integer_sequence<int, Js...>)
+{
+    (lead_one512<REV, Js>(y, ws), ...);
+}
+
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 // tw: the sub-transforms' thread-twiddle table (layout of upload_thread_twiddles_4096, radix 4, values W_4096^j = W_N^(R j));
@@ -122,6 +137,95 @@ __global__ __launch_bounds__(256, R == 2 ? 4 : 2) void sdsp_fft_mix_f32(float2 *
     }
 }
 
+// ---- N = 16384 = 4 x 4096 on a 512-thread workgroup: two halves of 256 threads, two sub-transforms each ---------------
+// The 256-thread form above needs 64 points per thread at R = 4 (192-198 VGPRs, two 4-wave workgroups per CU: 46 % of HBM
+// peak).  Here a thread holds 32: thread t < 512 loads x[t + 512 m], m < 32 -- the leading radix-4 stage's partners
+// n + 4096 r are still its own registers (m = j + 8 r) -- and the stage leaves y_q[t + 512 j], j < 8, for all four q.  Half
+// H = t >> 8 of the workgroup then runs the sub-transforms q = 2H, 2H + 1 in the tuned layout (thread tt = t & 255 holds
+// y_q[tt + 256 k], k < 16): k of one parity it already has, the other parity sits in thread t ^ 256, which wants exactly
+// the sixteen values this thread has no use for -- ONE pairwise exchange of 128 bytes per thread through LDS (the 64 KiB of
+// the two halves' FFT tiles, before they are needed).  Each half has its own 32 KiB tile; 64 data VGPRs; two 512-thread
+// workgroups per CU -- the footprint of four N = 8192 workgroups.  A lane stores X[4 (tt + 256 j) + 2H], + 1: 16 bytes at a
+// 32-byte stride; the other half of the workgroup writes the 16 bytes in between at the same time (the halves run in
+// lockstep), so the L2 sees whole lines.
+template <bool REV>
+__global__ __launch_bounds__(512, 4) void sdsp_fft_mix4_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                            const float2 *__restrict__ tws, uint64_t batch, float scale)
+{
+    constexpr uint32_t N = 16384;
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * 4096];
+    const uint32_t t = threadIdx.x, H = t >> 8, tt = t & 255;
+    float2 wA1[3], wA2[3], wB1[3], wB2[3], ws[3];
+    const uint32_t rr = tt & 15;
+#pragma unroll
+    for (int r = 1; r < 4; r++) { // see sdsp_fft4096_r4_f32
+        wA1[r - 1] = tw[(r - 1) * 256 + tt];
+        wA2[r - 1] = tw[(r + 2) * 256 + tt];
+        wB1[r - 1] = tw[1536 + (r - 1) * 16 + rr];
+        wB2[r - 1] = tw[1536 + (r + 2) * 16 + rr];
+        ws[r - 1] = tws[(r - 1) * 512 + t]; // W_N^(r t)
+    }
+    const lds_map mp = make_lds_map<false>(lds + 4096 * H, tt);
+
+    const uint64_t f = blockIdx.x;
+    if (f >= batch)
+        return;
+    float2 y[4][8]; // y[r][j] = x[t + 512 (j + 8 r)], then y_q[t + 512 j]
+    const float2 *src = data + f * N + t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            y[r][j] = gload(src + 512 * (j + 8 * r));
+    lead_stage512<REV>(y, ws, std::make_integer_sequence<int, 8>{});
+
+    // pairwise exchange with thread t ^ 256: it gets the two sub-transforms this half does not run
+    float2 z[2][16];
+    {
+        float2 *const xbuf = lds; // [16 values][512 threads]
+        if (H == 0) {
+#pragma unroll
+            for (int v = 0; v < 16; v++)
+                xbuf[v * 512 + t] = y[2 + (v >> 3)][v & 7];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; v++)
+                xbuf[v * 512 + t] = y[v >> 3][v & 7];
+        }
+        __syncthreads();
+        // own values: k of parity H; received: the other parity (y_q[tt + 256 k] lives in thread tt + 256 (k & 1), j = k >> 1)
+        if (H == 0) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                z[v >> 3][2 * (v & 7)] = y[v >> 3][v & 7];
+                z[v >> 3][2 * (v & 7) + 1] = xbuf[v * 512 + (t ^ 256)];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                z[v >> 3][2 * (v & 7) + 1] = y[2 + (v >> 3)][v & 7];
+                z[v >> 3][2 * (v & 7)] = xbuf[v * 512 + (t ^ 256)];
+            }
+        }
+        __syncthreads(); // the exchange buffer is the FFT tiles
+    }
+    fft4096_in_regs<REV, false>(z[0], lds + 4096 * H, mp, wA1, wA2, wB1, wB2);
+    fft4096_in_regs<REV, false>(z[1], lds + 4096 * H, mp, wA1, wA2, wB1, wB2);
+
+    // z[ql][k] = FFT(y_(2H+ql))[tt + 256 j], j = 4 (k & 3) + (k >> 2)  ->  X[4 (tt + 256 j) + 2H + ql]
+    float2 *dst = data + f * N + 4 * tt + 2 * H;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int j = 4 * (k & 3) + (k >> 2);
+        float2 a = z[0][k], b = z[1][k];
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            a.x *= scale, a.y *= scale, b.x *= scale, b.y *= scale;
+        }
+        const v4f_t v = { a.x, a.y, b.x, b.y };
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(dst + 4 * 256 * j));
+    }
+}
+
 template <int R> int launch_r(const fft_mix_args &a, hipStream_t s)
 {
     if (a.batch > 0x7fffffffull)
@@ -150,8 +254,20 @@ int launch_fft_mix_f32(const fft_mix_args &a, void *stream)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a.n == 8192)
         return launch_r<2>(a, s);
-    if (a.n == 16384)
-        return launch_r<4>(a, s);
+    if (a.n == 16384) {
+        if (a.batch > 0x7fffffffull)
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+        float2 *d = reinterpret_cast<float2 *>(a.data);
+        const float2 *tw = reinterpret_cast<const float2 *>(a.tw), *tws = reinterpret_cast<const float2 *>(a.tw_lead);
+        if (a.reverse)
+            hipLaunchKernelGGL(sdsp_fft_mix4_f32<true>, dim3((uint32_t)a.batch), dim3(512), 0, s, d, tw, tws, a.batch, a.scale);
+        else
+            hipLaunchKernelGGL(sdsp_fft_mix4_f32<false>, dim3((uint32_t)a.batch), dim3(512), 0, s, d, tw, tws, a.batch, a.scale);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return fail(SDSP_HIP_ERR_HIP, std::string("fft_mix launch: ") + hipGetErrorString(e));
+        return SDSP_HIP_OK;
+    }
     return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the mixed-radix kernels");
 }
 } // namespace sdsp_hip
