@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, R == 2 ? 4 : 2) void sdsp_fft_mix_f32(float2 *
 // the two halves' FFT tiles, before they are needed).  Each half has its own 32 KiB tile; 64 data VGPRs; two 512-thread
 // workgroups per CU -- the footprint of four N = 8192 workgroups.  A lane stores X[4 (tt + 256 j) + 2H], + 1: 16 bytes at a
 // 32-byte stride; the other half of the workgroup writes the 16 bytes in between at the same time (the halves run in
-// lockstep), so the L2 sees whole lines.
+// lockstep) -- which measured 28 % of HBM peak (partial sectors), so a second pairwise exchange regroups the results and
+// every lane stores 32 contiguous bytes.
 template <bool REV>
 __global__ __launch_bounds__(512, 4) void sdsp_fft_mix4_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                             const float2 *__restrict__ tws, uint64_t batch, float scale)
@@ -212,17 +213,44 @@ __global__ __launch_bounds__(512, 4) void sdsp_fft_mix4_f32(float2 *__restrict__
     fft4096_in_regs<REV, false>(z[0], lds + 4096 * H, mp, wA1, wA2, wB1, wB2);
     fft4096_in_regs<REV, false>(z[1], lds + 4096 * H, mp, wA1, wA2, wB1, wB2);
 
-    // z[ql][k] = FFT(y_(2H+ql))[tt + 256 j], j = 4 (k & 3) + (k >> 2)  ->  X[4 (tt + 256 j) + 2H + ql]
-    float2 *dst = data + f * N + 4 * tt + 2 * H;
+    // z[ql][k] = FFT(y_(2H+ql))[tt + 256 j], j = 4 (k & 3) + (k >> 2).  X[4 (tt + 256 j) + q], q < 4, are 32 contiguous bytes
+    // of which this thread holds q = 2H, 2H + 1 and its partner t ^ 256 the other two: a second pairwise exchange gives
+    // each thread all four for the j of one parity (H), so a lane stores 32 contiguous bytes (16-byte pieces of the two halves
+    // interleaved at a 32-byte stride measured 28 % of HBM peak: partial sectors).  Registers with (k >> 2) & 1 == H stay.
+    float2 other[2][8]; // the partner's sub-transforms, for this thread's eight j
+    {
+        float2 *const xbuf = lds; // [16 values][512 threads]; every LDS read of the sub-transforms is behind a barrier
+        if (H == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int j = 4 * (k & 3) + (k >> 2);
-        float2 a = z[0][k], b = z[1][k];
-        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
-            a.x *= scale, a.y *= scale, b.x *= scale, b.y *= scale;
+            for (int v = 0; v < 16; v++) // send odd j: k = 4 + (v & 3) + 8 ((v >> 2) & 1)
+                xbuf[v * 512 + t] = z[v >> 3][4 + (v & 3) + 8 * ((v >> 2) & 1)];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; v++) // send even j: k = (v & 3) + 8 ((v >> 2) & 1)
+                xbuf[v * 512 + t] = z[v >> 3][(v & 3) + 8 * ((v >> 2) & 1)];
         }
-        const v4f_t v = { a.x, a.y, b.x, b.y };
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(dst + 4 * 256 * j));
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            other[v >> 3][v & 7] = xbuf[v * 512 + (t ^ 256)];
+    }
+    float2 *dst = data + f * N + 4 * tt;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // this thread's i-th j: k = (i & 3) + 8 (i >> 2) + 4 H
+        const int kk = (i & 3) + 8 * (i >> 2);
+        float2 mine0 = H ? z[0][kk + 4] : z[0][kk], mine1 = H ? z[1][kk + 4] : z[1][kk];
+        float2 o0 = other[0][i], o1 = other[1][i];
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            mine0.x *= scale, mine0.y *= scale, mine1.x *= scale, mine1.y *= scale;
+            o0.x *= scale, o0.y *= scale, o1.x *= scale, o1.y *= scale;
+        }
+        // q = 0, 1 belong to half 0, q = 2, 3 to half 1
+        const v4f_t lo = H ? v4f_t{ o0.x, o0.y, o1.x, o1.y } : v4f_t{ mine0.x, mine0.y, mine1.x, mine1.y };
+        const v4f_t hi = H ? v4f_t{ mine0.x, mine0.y, mine1.x, mine1.y } : v4f_t{ o0.x, o0.y, o1.x, o1.y };
+        const int k = kk; // j of register k (either half): 4 (k & 3) + (k >> 2), + 1 for the odd half
+        float2 *q = dst + 4 * 256 * (4 * (k & 3) + (k >> 2)) + 4 * 256 * (int)H;
+        __builtin_nontemporal_store(lo, reinterpret_cast<v4f_t *>(q));
+        __builtin_nontemporal_store(hi, reinterpret_cast<v4f_t *>(q + 2));
     }
 }
 
