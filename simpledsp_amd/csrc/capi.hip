@@ -591,7 +591,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!sdsp_hip_is_power_of_2(n))
             return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
         // the stage type of the fastest kernel of the size: radix 4 where n is a power of 4 -- except n = 16384, where the
-        // radix-2-stage kernel (fft_big.hip, 59 % of HBM peak) beats the radix-4 one (fft_mix.hip at 2 workgroups per CU, 46 %)
+        // radix-2-stage kernel (fft_big.hip) and the radix-4 one (fft_mix.hip) measure the same 58-61 % of HBM peak
         radix = (sdsp_hip_is_power_of_4(n) && n != 16384) ? 4 : 2;
     }
     // the reference's static_asserts (fft.h:261, :304) as run-time checks
