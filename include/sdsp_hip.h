@@ -163,6 +163,19 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int r
  * for plans whose kernels have no in-kernel hand-off).  Has no reference counterpart. */
 int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
 
+/* Launch granularity (process-wide; has no reference counterpart).  A batch of transforms whose buffer is larger than
+ * 1.5 x `bytes` is issued as consecutive launches over pieces of at most `bytes` of the buffer, in stream order (same bits,
+ * same single call).  Why: workgroups are dealt to the eight XCDs round-robin and the XCDs drift apart over a long launch, so
+ * the window of DRAM pages the chip works on widens.  Measured on the N = 4096 kernel: one launch over 8 GiB 72.1 % of HBM
+ * peak, the same buffer in 2 GiB pieces 75.4 %, in 1 GiB pieces 76.3 %, 512 MiB 75.8 %, 256 MiB 74.4 % (DESIGN.md section
+ * 5.1c).  Applies to the FFT kernels that cover a batch with one launch, N <= 8192 (many short workgroups); not to
+ * N = 16384 / 32768 (one or two transforms fill a CU: pieces cost 1.6 points there), not to the multi-pass sizes (they chunk
+ * by their workspace) and not to the IIR / FIR kernels (a workgroup there walks whole rows for milliseconds: pieces only add launch
+ * tails -- 70.0 % in one launch, 68.7 / 66.4 / 45.2 % in 2 GiB / 1 GiB / 512 MiB pieces).  bytes = 0: never split. */
+#define SDSP_HIP_DEFAULT_PIECE_BYTES (1ull << 30)
+int sdsp_hip_set_launch_piece_bytes(uint64_t bytes);
+int sdsp_hip_get_launch_piece_bytes(uint64_t *bytes);
+
 typedef struct {
     uint32_t n;
     int radix;

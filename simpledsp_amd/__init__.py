@@ -12,6 +12,20 @@ from .iir import casc_2o_iir, casc_2o_iir_lp, casc_2o_iir_hp, casc_2o_iir_bp
 from .fir import fir_filter
 
 
+def set_launch_piece_bytes(nbytes: int) -> None:
+    """Process-wide launch granularity (include/sdsp_hip.h: sdsp_hip_set_launch_piece_bytes); 0 = never split."""
+    from ._lib import check
+    check(load().sdsp_hip_set_launch_piece_bytes(int(nbytes)))
+
+
+def get_launch_piece_bytes() -> int:
+    import ctypes
+    from ._lib import check
+    v = ctypes.c_uint64(0)
+    check(load().sdsp_hip_get_launch_piece_bytes(ctypes.byref(v)))
+    return v.value
+
+
 class filter_type:  # filter_type.h:6
     none, low_pass, high_pass, band_pass = 0, 1, 2, 3
     band_stop = 4  # not in the reference's enum (README.md:15 TODO)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sdsp_hip_fft_plan_get_twiddles": (_i, [_vp, _vp]),
     "sdsp_hip_fft_plan_set_variant": (_i, [_vp, _i]),
     "sdsp_hip_fft_plan_status": (_i, [_vp]),
+    "sdsp_hip_set_launch_piece_bytes": (_i, [_u64]),
+    "sdsp_hip_get_launch_piece_bytes": (_i, [C.POINTER(_u64)]),
     "sdsp_hip_iir_design_lp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_hp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
     "sdsp_hip_iir_design_bp": (_i, [_u32, _d, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),

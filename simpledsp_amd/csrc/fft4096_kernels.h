@@ -221,7 +221,9 @@ __device__ __forceinline__ void lds_read_c(const float2 *lds, const lds_map &mp,
 //   LORD  order of the 16 row loads: 0 ascending, 1 bit-reversed, 2 the order the first butterflies consume them
 //   LDSB  order of pass B's LDS reads: 0 ascending, 1 consumption order
 //   WAVES launch bound (waves per SIMD the register allocator must leave room for)
-template <bool REV, int BAR, int SORD, int LORD, int LDSB, int WAVES>
+//   MAP   0: workgroup b transforms row b; 1 (lab only, batch % 8 == 0): the workgroups of XCD b % 8 walk their own
+//         contiguous eighth of the batch
+template <bool REV, int BAR, int SORD, int LORD, int LDSB, int WAVES, int MAP = 0>
 __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                   uint64_t batch, float scale)
 {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     }
     const lds_map mp = make_lds_map<false>(lds, t);
 
-    const uint64_t f = blockIdx.x;
+    const uint64_t f = MAP == 1 ? (blockIdx.x & 7u) * (batch >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     if (f >= batch)
         return;
     float2 x[16];

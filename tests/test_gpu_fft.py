@@ -576,3 +576,40 @@ def test_plans_on_a_second_device(sd, torch_cuda, oracle):
             assert rel_max_err(d.cpu().numpy(), want) < TOL32, (n, dev)
         with pytest.raises(ValueError):
             plan.exec(torch.from_numpy(x).to("cuda:0"))  # plan on device 1, tensor on device 0
+
+
+@pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1000), (4096, 2, "f32", 777), (64, 2, "f32", 70001),
+                                                     (8, 2, "f32", 20000), (8192, 0, "f32", 300), (32768, 2, "f32", 67),
+                                                     (1024, 4, "f64", 1500), (100, 2, "f32", 0)])
+def test_launch_pieces_are_bit_identical(sd, torch_cuda, n, radix, precision, batch):
+    """sdsp_hip_set_launch_piece_bytes (include/sdsp_hip.h): a batch issued as several launches over consecutive pieces of
+    the buffer gives the bits of the single launch -- ragged last pieces, pieces that are rounded to a workgroup's tile
+    (N = 8: 4096 transforms), every single-launch kernel family."""
+    torch = torch_cuda
+    if n == 100:  # not a power of two: no plan; the knob itself round-trips
+        old = sd.get_launch_piece_bytes()
+        sd.set_launch_piece_bytes(12345)
+        assert sd.get_launch_piece_bytes() == 12345
+        sd.set_launch_piece_bytes(old)
+        return
+    prec = sd.F64 if precision == "f64" else sd.F32
+    dt = torch.complex128 if precision == "f64" else torch.complex64
+    g = torch.Generator(device="cuda").manual_seed(n + batch)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device="cuda", dtype=torch.float64 if precision == "f64" else torch.float32))
+    old = sd.get_launch_piece_bytes()
+    try:
+        outs = []
+        for piece in (0, 1 << 20, 3 << 20):
+            sd.set_launch_piece_bytes(piece)
+            for T in (sd.forward_fft, sd.reverse_fft):
+                p = sd.FftPlan(n, radix, T, prec, max_batch=batch)
+                d = x.clone().to(dt)
+                p.exec(d)
+                torch.cuda.synchronize()
+                outs.append((piece, T.__name__, d.cpu().numpy()))
+                p.close()
+        for piece, tname, o in outs[2:]:
+            ref = outs[0][2] if tname == "forward_fft" else outs[1][2]
+            assert np.array_equal(o, ref), (n, radix, piece, tname)
+    finally:
+        sd.set_launch_piece_bytes(old)

@@ -370,3 +370,4 @@ def test_randomised_cross_check(torch_cuda):
     from conftest import ROOT
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_crosscheck.py"), "7", "150"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+

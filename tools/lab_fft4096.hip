@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
+#include <algorithm>
 
 #include "fft4096_kernels.h"
 
@@ -70,10 +72,99 @@ __global__ void checksum_kernel(const uint2 *p, size_t n, unsigned long long *ou
     atomicAdd(out, acc);
 }
 
+// Where does the rate go when the buffer grows?  One buffer of `batch` transforms, the product
+// instance, forward / reverse alternating:
+//   whole      one launch over the whole buffer
+//   pieces     the same buffer in launches of 65536 transforms (launch length held, address range grows)
+//   first      launches of 65536 transforms on the first piece only (both held)
+//   whole xcd  one launch, every XCD walking its own contiguous eighth
+static int size_study(uint64_t batch, int rounds)
+{
+    const size_t n = batch * 4096;
+    float2 *data, *tw;
+    CK(hipMalloc(&data, n * 8));
+    std::vector<float2> t4[2];
+    auto W = [](uint32_t idx, bool rev) {
+        const double a = (rev ? 2.0 : -2.0) * M_PI * (double)(idx & 4095) / 4096.0;
+        return float2{ (float)std::cos(a), (float)std::sin(a) };
+    };
+    for (int rev = 0; rev < 2; rev++) {
+        for (uint32_t mult : { 1u, 4u })
+            for (uint32_t r = 1; r < 4; r++)
+                for (uint32_t t = 0; t < 256; t++)
+                    t4[rev].push_back(W(mult * r * t, rev));
+        for (uint32_t mult : { 16u, 64u })
+            for (uint32_t r = 1; r < 4; r++)
+                for (uint32_t rr = 0; rr < 16; rr++)
+                    t4[rev].push_back(W(mult * r * rr, rev));
+    }
+    CK(hipMalloc(&tw, 2 * t4[0].size() * 8));
+    for (int rev = 0; rev < 2; rev++)
+        CK(hipMemcpy(tw + rev * t4[0].size(), t4[rev].data(), t4[rev].size() * 8, hipMemcpyHostToDevice));
+    const float2 *twf = tw, *twr = tw + t4[0].size();
+    const float scale = 1.0f / 4096.0f;
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, data, n, 9u);
+    const uint64_t piece = 65536;
+    auto run = [&](int mode, bool rev) {
+        const float2 *w = rev ? twr : twf;
+        if (mode == 0) {
+            if (rev)
+                hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, 1, 2, 0, 0, 3>), dim3((uint32_t)batch), dim3(256), 0, 0, data, w, batch, scale);
+            else
+                hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, 1, 2, 0, 0, 3>), dim3((uint32_t)batch), dim3(256), 0, 0, data, w, batch, scale);
+        } else if (mode == 3) {
+            if (rev)
+                hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, 1, 2, 0, 0, 3, 1>), dim3((uint32_t)batch), dim3(256), 0, 0, data, w, batch, scale);
+            else
+                hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, 1, 2, 0, 0, 3, 1>), dim3((uint32_t)batch), dim3(256), 0, 0, data, w, batch, scale);
+        } else {
+            for (uint64_t off = 0; off < batch; off += piece) {
+                float2 *d = data + (mode == 1 ? off : 0) * 4096;
+                const uint64_t b = std::min(piece, batch - off);
+                if (rev)
+                    hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, 1, 2, 0, 0, 3>), dim3((uint32_t)b), dim3(256), 0, 0, d, w, b, scale);
+                else
+                    hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, 1, 2, 0, 0, 3>), dim3((uint32_t)b), dim3(256), 0, 0, d, w, b, scale);
+            }
+        }
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const char *names[4] = { "whole", "pieces", "first", "whole xcd" };
+    for (int i = 0; i < 30; i++) {
+        run(2, false);
+        run(2, true);
+    }
+    std::printf("batch %llu = %.1f GiB\n", (unsigned long long)batch, (double)n * 8 / (1 << 30));
+    for (int round = 0; round < rounds; round++)
+        for (int mode = 0; mode < 4; mode++) {
+            for (int i = 0; i < 3; i++) {
+                run(mode, false);
+                run(mode, true);
+            }
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 6; i++) {
+                run(mode, false);
+                run(mode, true);
+            }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double per = ms / 12.0;
+            std::printf("%-10s %.4f ms per pass over the buffer, %5.2f %%\n", names[mode], per, (double)batch * 65536.0 / (per * 1e-3) / 8e12 * 100.0);
+            std::fflush(stdout);
+        }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const uint64_t batch = argc > 1 ? (uint64_t)std::atoll(argv[1]) : 65536;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 2;
+    if (argc > 3 && std::string(argv[3]) == "size")
+        return size_study(batch, rounds);
     add_sord<0>();
     add_sord<1>();
     add_sord<2>();
