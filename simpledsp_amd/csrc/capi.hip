@@ -352,6 +352,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.nontemporal = variant != 1 || mix_size; // 1: default cache policy (N < 8192)
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
+        if (variant == 0 && !p->real_mode && fft_wave_supports(p->n, p->radix)) // N = 1024: one transform per wave
+            return launch_fft_wave_f32(a, stream);
         return launch_fft_reg_f32(a, stream);
     }
 
@@ -985,6 +987,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode && fft_wave_supports(p->n, p->radix))
+        name = "sdsp_fft1024_wave_f32";
     if (big)
         name = "sdsp_fft_big_kernel";
     if (mix_size && p->variant == 0)

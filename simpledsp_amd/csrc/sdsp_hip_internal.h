@@ -93,6 +93,9 @@ int launch_fft_reg_f32(const fft_reg_args &a, void *stream);
 bool fft_reg64_supports(uint32_t n, int radix); // f64 family: 16 .. 8192
 int launch_fft_reg_f64(const fft_reg_args &a, void *stream);
 // N = 8192 / 16384 / 32768, radix 2, f32: transform held in registers, LDS only for the exchanges (fft_big.hip)
+// N = 1024 f32, one transform per wave (fft_wave.hip); a.tw = the register-pass thread-twiddle table
+bool fft_wave_supports(uint32_t n, int radix);
+int launch_fft_wave_f32(const fft_reg_args &a, void *stream);
 bool fft_big_supports(uint32_t n, int radix);
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 

@@ -118,7 +118,7 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
 
 
 @pytest.mark.parametrize("n,radix,batch", [(16, 2, 1), (16, 4, 300), (32, 2, 129), (64, 4, 1000), (128, 2, 33), (256, 4, 17),
-                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (2048, 2, 3), (4096, 2, 5),
+                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
                                            (8192, 2, 3), (16384, 2, 2), (16384, 4, 3)])
 def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
     # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
@@ -131,10 +131,12 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
         big = n >= 8192  # radix 2: registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
         mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
-                                             "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
+                                             "sdsp_fft_big_kernel" if big else
+                                             "sdsp_fft1024_wave_f32" if n == 1024 else "sdsp_fft_reg_kernel")  # csrc/fft_wave.hip: one transform per wave
         outs = []
         # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel (, the size's tuned kernel)
-        for variant in ((2, 1, 99, 0) if (n, radix) == (4096, 2) or big else (0, 1, 99)):
+        # N = 1024: variant 0 is the one-wave kernel, which runs the register-pass family's arithmetic: the same bits
+        for variant in ((2, 1, 99, 0) if (n, radix) == (4096, 2) or big else (0, 1, 99, 2) if n == 1024 else (0, 1, 99)):
             plan.set_variant(variant)
             d = torch.from_numpy(x).cuda()
             guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector

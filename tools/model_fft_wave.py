@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""tools/model_fft_wave.py -- LDS slot map of csrc/fft_wave.hip (N = 1024, one transform per wave).
+
+A wave exchanges its 1024 points through LDS twice; the three access patterns (8-byte units, lane t, register index):
+  A  p = t + 64 k                  written after pass A
+  B  p = 64 (t >> 2) + (t & 3) + 4 j   read before / written after pass B
+  C  p = 16 w(t) + i               read before pass C, w = bit_reverse6(t) (radix 2) or digit_reverse4(t) (radix 4)
+ds_read/write_b64 are serviced per half-wave over 32 bank pairs (slot mod 32).  Slots are p ^ X(p >> 5) with X linear over
+GF(2) (five rows of five bits): this script searches rows for which every pattern of BOTH radices puts the 32 lanes of each
+half-wave on 32 distinct bank pairs, and verifies the rows compiled into the kernel (kRow).
+"""
+import random
+
+K_ROW = [2, 30, 15, 25, 26]  # csrc/fft_wave.hip: kRow
+
+
+def brev6(t):
+    return int(f"{t:06b}"[::-1], 2)
+
+
+def drev3(t):
+    return ((t & 3) << 4) | (t & 12) | ((t >> 4) & 3)
+
+
+def patterns(radix):
+    pats = [[t + 64 * k for t in range(64)] for k in range(16)]
+    pats += [[64 * (t >> 2) + (t & 3) + 4 * j for t in range(64)] for j in range(16)]
+    w = brev6 if radix == 2 else drev3
+    pats += [[16 * w(t) + i for t in range(64)] for i in range(16)]
+    return pats
+
+
+def slot(rows, p):
+    x = 0
+    for b in range(5):
+        if (p >> (5 + b)) & 1:
+            x ^= rows[b]
+    return p ^ x
+
+
+def conflict_free(rows, pats):
+    return all(len({slot(rows, p) & 31 for p in pat[h:h + 32]}) == 32 for pat in pats for h in (0, 32))
+
+
+if __name__ == "__main__":
+    p2, p4 = patterns(2), patterns(4)
+    assert conflict_free(K_ROW, p2) and conflict_free(K_ROW, p4), "the compiled rows are not conflict free"
+    ident = [0, 0, 0, 0, 0]
+    worst = max(32 // len({p & 31 for p in pat[:32]}) for pat in p2 + p4)
+    print(f"kRow = {K_ROW}: conflict free for both radices (no swizzle: up to {worst}-way conflicts)")
+    # every slot is used exactly once
+    assert sorted(slot(K_ROW, p) for p in range(1024)) == list(range(1024))
+    random.seed(1)
+    for it in range(100000):
+        rows = [random.randrange(32) for _ in range(5)]
+        if conflict_free(rows, p2) and conflict_free(rows, p4):
+            print(f"search: rows {rows} after {it + 1} draws")
+            break
