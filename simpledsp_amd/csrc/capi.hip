@@ -324,7 +324,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_big_f32(a, stream);
     }
 
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && variant == 0) {
+    const bool wave64 = p->path == PATH_REG && p->precision == SDSP_HIP_F64 && !p->real_mode && fft_wave_supports(p->n, p->radix);
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && (variant == 0 || (variant == 1 && wave64))) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;
@@ -337,6 +338,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.nontemporal = 1;
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
+        if (wave64 && variant == 1) // N = 1024 alternate: one transform per wave (same bits; measured 71.4-72.1 % against
+            return launch_fft_wave_f64(a, stream); // 71.7-72.6 % for the register-pass kernel: no gain in double)
         return launch_fft_reg_f64(a, stream);
     }
 
@@ -987,8 +990,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode && fft_wave_supports(p->n, p->radix))
-        name = "sdsp_fft1024_wave_f32";
+    if (p->path == PATH_REG && p->variant == (p->precision == SDSP_HIP_F64 ? 1 : 0) && !p->real_mode && fft_wave_supports(p->n, p->radix))
+        name = "sdsp_fft1024_wave";
     if (big)
         name = "sdsp_fft_big_kernel";
     if (mix_size && p->variant == 0)

@@ -1,5 +1,6 @@
-// fft_wave.hip -- batched N = 1024 complex f32 FFT, radix-2 (fft.h:258-299) or radix-4 (fft.h:301-360) stages, one
-// transform per WAVE, for gfx950.
+// fft_wave.hip -- batched N = 1024 complex FFT (f32 and f64), radix-2 (fft.h:258-299) or radix-4 (fft.h:301-360) stages,
+// one transform per WAVE, for gfx950.  (N = 1024 in double is the reference's own test point, testFFT.cpp:239 / BASELINE
+// config 1.)
 //
 // The register-pass family (fft_reg.hip) stages a 4096-point block through LDS with a 16-byte copy phase on either side
 // of its in-LDS passes and three workgroup barriers; at N = 1024 it reads 68.7-71.4 % of HBM peak.  N = 1024 = 64 lanes x
@@ -20,8 +21,9 @@
 // register-pass family: the results are bit-identical to it (tests/test_gpu_fft.py holds both to the oracle and to
 // each other).
 //
-// LDS slots (8-byte units) are p ^ X(p >> 5) with X linear over GF(2), chosen by search (tools/model_fft_wave.py) so that
-// all three access patterns of both radices hit 32 distinct 8-byte bank pairs in each half-wave.
+// LDS slots (units of one complex element) are p ^ X(p >> SH) with X linear over GF(2), chosen by search
+// (tools/model_fft_wave.py) so that all three access patterns of both radices are conflict-free: f32 (ds_*_b64, SH = 5): 32
+// distinct 8-byte bank pairs in each half-wave; f64 (ds_*_b128, SH = 4): 16 distinct 16-byte bank quads in each quarter-wave.
 #include <hip/hip_runtime.h>
 
 #include "fft_passes.h"
@@ -32,6 +34,7 @@ namespace sdsp_hip
 namespace
 {
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 gload(const float2 *p)
 {
     const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(p));
@@ -41,41 +44,57 @@ __device__ __forceinline__ void gstore(float2 *p, float2 a)
 {
     __builtin_nontemporal_store(v2f_t{ a.x, a.y }, reinterpret_cast<v2f_t *>(p));
 }
+__device__ __forceinline__ double2 gload(const double2 *p)
+{
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return double2{ v.x, v.y };
+}
+__device__ __forceinline__ void gstore(double2 *p, double2 a)
+{
+    __builtin_nontemporal_store(v2d_t{ a.x, a.y }, reinterpret_cast<v2d_t *>(p));
+}
 
-// X(h) for h = p >> 5 (five bits): XOR of the rows of the bits set in h
-constexpr uint32_t kRow[5] = { 2, 30, 15, 25, 26 };
-constexpr uint32_t xterm(uint32_t h)
+// X(h) for h = p >> SH (10 - SH bits): XOR of the rows of the bits set in h.  SH = 5: float2, SH = 4: double2
+template <int SH> struct rows;
+template <> struct rows<5> {
+    static constexpr uint32_t r[6] = { 2, 30, 15, 25, 26, 0 };
+};
+template <> struct rows<4> {
+    static constexpr uint32_t r[6] = { 7, 15, 8, 15, 11, 14 };
+};
+template <int SH> constexpr uint32_t xterm(uint32_t h)
 {
     uint32_t x = 0;
-    for (int b = 0; b < 5; b++)
+    for (int b = 0; b < 10 - SH; b++)
         if ((h >> b) & 1)
-            x ^= kRow[b];
+            x ^= rows<SH>::r[b];
     return x;
 }
-__device__ __forceinline__ uint32_t xterm_dev(uint32_t h)
+template <int SH> __device__ __forceinline__ uint32_t xterm_dev(uint32_t h)
 {
     uint32_t x = 0;
 #pragma unroll
-    for (int b = 0; b < 5; b++)
-        x ^= ((h >> b) & 1) ? kRow[b] : 0u;
+    for (int b = 0; b < 10 - SH; b++)
+        x ^= ((h >> b) & 1) ? rows<SH>::r[b] : 0u;
     return x;
 }
 
-template <int RADIX, bool REV>
-__global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict__ data, const float2 *__restrict__ tw, uint64_t batch,
-                                                             float scale)
+// WAVES: transforms (= waves) per workgroup: 4 in f32 (32 KiB of LDS), 2 in f64 (32 KiB)
+template <typename C, typename S, int RADIX, bool REV, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ data, const C *__restrict__ tw, uint64_t batch, S scale)
 {
-    __shared__ __attribute__((aligned(16))) float2 lds_all[4][1024];
+    constexpr int SH = sizeof(C) == 8 ? 5 : 4;
+    __shared__ __attribute__((aligned(16))) C lds_all[WAVES][1024];
     const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float2 *lds = lds_all[wave];
-    const uint64_t f = static_cast<uint64_t>(blockIdx.x) * 4 + wave;
+    C *lds = lds_all[wave];
+    const uint64_t f = static_cast<uint64_t>(blockIdx.x) * WAVES + wave;
     if (f >= batch)
         return; // wave-uniform; the kernel has no barrier
     // thread twiddles: [pass][value][thread], 64 threads per transform (fft_reg.hip: twl)
     auto twl = [&](int pass, int v) { return tw[(6 * pass + v) * 64 + t]; };
 
-    float2 x[16];
-    const float2 *src = data + f * 1024 + t;
+    C x[16];
+    const C *src = data + f * 1024 + t;
 #pragma unroll
     for (int k = 0; k < 16; k++)
         x[k] = gload(src + 64 * k);
@@ -83,7 +102,7 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
     auto run_pass = [&](auto pass_tag) {
         constexpr int I = decltype(pass_tag)::value;
         if constexpr (RADIX == 2) {
-            float2 w[4];
+            C w[4];
             if constexpr (I < 2) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
             }
             passes::r2_pass<REV, (I < 2), (I == 2 ? 2 : 0)>::run(x, w);
         } else {
-            float2 w1[3], w2[3];
+            C w1[3], w2[3];
             if constexpr (I < 2) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -105,22 +124,22 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
 
     run_pass(std::integral_constant<int, 0>{});
 
-    // ---- exchange A -> B.  A: p = t + 64 k, p >> 5 = (t >> 5) + 2 k
+    // ---- exchange A -> B.  A: p = t + 64 k, p >> SH = (t >> SH) | (k << (6 - SH))
     {
-        uint32_t ta = t ^ ((t >> 5) ? kRow[0] : 0u);
+        uint32_t ta = t ^ xterm_dev<SH>(t >> SH);
         asm volatile("" : "+v"(ta)); // one v_xor per access instead of sixteen live addresses
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            lds[64 * k + (ta ^ xterm(2u * k))] = x[k];
+            lds[64 * k + (ta ^ xterm<SH>((uint32_t)k << (6 - SH)))] = x[k];
     }
-    // B: p = 64 b + v + 4 j, p >> 5 = 2 b + (j >> 3)
-    uint32_t tb = 64u * (t >> 2) + ((t & 3u) ^ xterm_dev(2u * (t >> 2)));
+    // B: p = 64 b + v + 4 j, p >> SH = (b << (6 - SH)) | (j >> (SH - 2))
+    uint32_t tb = 64u * (t >> 2) + ((t & 3u) ^ xterm_dev<SH>((t >> 2) << (6 - SH)));
     {
         uint32_t a = tb;
         asm volatile("" : "+v"(a));
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            x[j] = lds[a ^ ((4u * j) ^ xterm(j >> 3))];
+            x[j] = lds[a ^ ((4u * j) ^ xterm<SH>((uint32_t)j >> (SH - 2)))];
     }
 
     run_pass(std::integral_constant<int, 1>{});
@@ -131,12 +150,12 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
         asm volatile("" : "+v"(a));
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            lds[a ^ ((4u * j) ^ xterm(j >> 3))] = x[j];
+            lds[a ^ ((4u * j) ^ xterm<SH>((uint32_t)j >> (SH - 2)))] = x[j];
     }
-    // C: p = 16 w + i, p >> 5 = w >> 1; w = reversed(t) so that the outputs land at t + 64 * reversed(i)
+    // C: p = 16 w + i, p >> SH = w >> (SH - 4); w = reversed(t) so that the outputs land at t + 64 * reversed(i)
     const uint32_t w = RADIX == 2 ? (__brev(t) >> 26) : (((t & 3u) << 4) | (t & 12u) | (t >> 4));
     {
-        uint32_t a = (16u * w) ^ xterm_dev(w >> 1);
+        uint32_t a = (16u * w) ^ xterm_dev<SH>(w >> (SH - 4));
         asm volatile("" : "+v"(a));
 #pragma unroll
         for (int i = 0; i < 16; i++)
@@ -145,10 +164,10 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
 
     run_pass(std::integral_constant<int, 2>{});
 
-    float2 *dst = data + f * 1024 + t;
+    C *dst = data + f * 1024 + t;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        float2 v = x[i];
+        C v = x[i];
         if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
             v.x *= scale;
             v.y *= scale;
@@ -158,17 +177,25 @@ __global__ __launch_bounds__(256) void sdsp_fft1024_wave_f32(float2 *__restrict_
     }
 }
 
-template <int RADIX, bool REV> int launch_t(const fft_reg_args &a, hipStream_t s)
+template <typename C, typename S, int RADIX, bool REV> int launch_t(const fft_reg_args &a, S scale, hipStream_t s)
 {
-    const uint64_t blocks = (a.batch + 3) / 4;
+    constexpr int WAVES = sizeof(C) == 8 ? 4 : 2;
+    const uint64_t blocks = (a.batch + WAVES - 1) / WAVES;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL((sdsp_fft1024_wave_f32<RADIX, REV>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
-                       reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale);
+    hipLaunchKernelGGL((sdsp_fft1024_wave<C, S, RADIX, REV, WAVES>), dim3((uint32_t)blocks), dim3(64 * WAVES), 0, s,
+                       reinterpret_cast<C *>(a.data), reinterpret_cast<const C *>(a.tw), a.batch, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_wave launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
+}
+
+template <typename C, typename S> int launch_c(const fft_reg_args &a, S scale, hipStream_t s)
+{
+    if (a.radix == 2)
+        return a.reverse ? launch_t<C, S, 2, true>(a, scale, s) : launch_t<C, S, 2, false>(a, scale, s);
+    return a.reverse ? launch_t<C, S, 4, true>(a, scale, s) : launch_t<C, S, 4, false>(a, scale, s);
 }
 } // namespace
 
@@ -177,16 +204,22 @@ bool fft_wave_supports(uint32_t n, int radix)
     return n == 1024 && (radix == 2 || radix == 4);
 }
 
-// a.tw: the plan's register-pass thread-twiddle table (twt_reg)
+// a.tw: the plan's register-pass thread-twiddle table (twt_reg), in the plan's precision
 int launch_fft_wave_f32(const fft_reg_args &a, void *stream)
 {
     if (a.batch == 0)
         return SDSP_HIP_OK;
     if (!fft_wave_supports(a.n, a.radix))
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the one-wave kernels");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a.radix == 2)
-        return a.reverse ? launch_t<2, true>(a, s) : launch_t<2, false>(a, s);
-    return a.reverse ? launch_t<4, true>(a, s) : launch_t<4, false>(a, s);
+    return launch_c<float2, float>(a, a.scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+int launch_fft_wave_f64(const fft_reg_args &a, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    if (!fft_wave_supports(a.n, a.radix))
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the one-wave kernels");
+    return launch_c<double2, double>(a, a.scale_d, reinterpret_cast<hipStream_t>(stream));
 }
 } // namespace sdsp_hip

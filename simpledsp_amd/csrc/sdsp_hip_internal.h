@@ -96,6 +96,7 @@ int launch_fft_reg_f64(const fft_reg_args &a, void *stream);
 // N = 1024 f32, one transform per wave (fft_wave.hip); a.tw = the register-pass thread-twiddle table
 bool fft_wave_supports(uint32_t n, int radix);
 int launch_fft_wave_f32(const fft_reg_args &a, void *stream);
+int launch_fft_wave_f64(const fft_reg_args &a, void *stream); // scale_d
 bool fft_big_supports(uint32_t n, int radix);
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 

@@ -132,7 +132,7 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
         mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
                                              "sdsp_fft_big_kernel" if big else
-                                             "sdsp_fft1024_wave_f32" if n == 1024 else "sdsp_fft_reg_kernel")  # csrc/fft_wave.hip: one transform per wave
+                                             "sdsp_fft1024_wave" if n == 1024 else "sdsp_fft_reg_kernel")  # csrc/fft_wave.hip: one transform per wave
         outs = []
         # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel (, the size's tuned kernel)
         # N = 1024: variant 0 is the one-wave kernel, which runs the register-pass family's arithmetic: the same bits
@@ -615,3 +615,30 @@ def test_launch_pieces_are_bit_identical(sd, torch_cuda, n, radix, precision, ba
             assert np.array_equal(o, ref), (n, radix, piece, tname)
     finally:
         sd.set_launch_piece_bytes(old)
+
+
+@pytest.mark.parametrize("radix,batch", [(2, 1), (2, 257), (4, 3), (4, 1000)])
+def test_one_wave_kernel_f64(sd, torch_cuda, oracle, radix, batch):
+    """N = 1024 in double -- the reference's own test point (testFFT.cpp:239, BASELINE config 1) -- has the one-transform-per-wave
+    kernel (csrc/fft_wave.hip) as its variant 1; the f64 register-pass kernel (variant 0, the default: the wave kernel gains
+    nothing in double) computes the same arithmetic: same bits.
+    Both are held to the reference's bound 4 N eps against the oracle; ragged batches (two waves per workgroup)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1024 + batch)
+    x = rng.standard_normal((batch, 1024)) + 1j * rng.standard_normal((batch, 1024))
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        want = oracle.fft(x, radix, rev)
+        plan = sd.FftPlan(1024, radix, T, sd.F64, max_batch=batch)
+        assert plan.info.kernel.decode() == "sdsp_fft_reg_f64_kernel"
+        outs = []
+        for variant in (0, 1):
+            plan.set_variant(variant)
+            d = torch.from_numpy(x).cuda()
+            guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex128, device="cuda")
+            plan.exec(d)
+            torch.cuda.synchronize()
+            outs.append(d.cpu().numpy())
+            assert np.abs(outs[-1] - want).max() < _tol64(1024) * max(1.0, np.abs(want).max()), (radix, rev, variant)
+            assert bool((guard == 7.0 + 3.0j).all())
+        assert plan.info.kernel.decode() == "sdsp_fft1024_wave"
+        assert np.array_equal(outs[0], outs[1])

@@ -11,7 +11,8 @@ half-wave on 32 distinct bank pairs, and verifies the rows compiled into the ker
 """
 import random
 
-K_ROW = [2, 30, 15, 25, 26]  # csrc/fft_wave.hip: kRow
+K_ROW = [2, 30, 15, 25, 26]  # csrc/fft_wave.hip: rows<5> (float2: 8-byte units, X of p >> 5)
+K_ROW64 = [7, 15, 8, 15, 11, 14]  # rows<4> (double2: 16-byte units, X of p >> 4; ds_*_b128: quarter-waves over 16 bank quads)
 
 
 def brev6(t):
@@ -30,16 +31,17 @@ def patterns(radix):
     return pats
 
 
-def slot(rows, p):
+def slot(rows, p, sh=5):
     x = 0
-    for b in range(5):
-        if (p >> (5 + b)) & 1:
+    for b in range(10 - sh):
+        if (p >> (sh + b)) & 1:
             x ^= rows[b]
     return p ^ x
 
 
-def conflict_free(rows, pats):
-    return all(len({slot(rows, p) & 31 for p in pat[h:h + 32]}) == 32 for pat in pats for h in (0, 32))
+def conflict_free(rows, pats, sh=5):
+    lanes = 1 << sh  # 32 lanes over 32 bank pairs (b64) / 16 lanes over 16 bank quads (b128)
+    return all(len({slot(rows, p, sh) & (lanes - 1) for p in pat[h:h + lanes]}) == lanes for pat in pats for h in range(0, 64, lanes))
 
 
 if __name__ == "__main__":
@@ -50,6 +52,9 @@ if __name__ == "__main__":
     print(f"kRow = {K_ROW}: conflict free for both radices (no swizzle: up to {worst}-way conflicts)")
     # every slot is used exactly once
     assert sorted(slot(K_ROW, p) for p in range(1024)) == list(range(1024))
+    assert conflict_free(K_ROW64, p2, 4) and conflict_free(K_ROW64, p4, 4), "the compiled f64 rows are not conflict free"
+    assert sorted(slot(K_ROW64, p, 4) for p in range(1024)) == list(range(1024))
+    print(f"rows<4> = {K_ROW64}: conflict free for both radices (f64, quarter-waves)")
     random.seed(1)
     for it in range(100000):
         rows = [random.randrange(32) for _ in range(5)]
