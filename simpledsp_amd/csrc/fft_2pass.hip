@@ -47,32 +47,24 @@ template <int L, bool REV> __device__ __forceinline__ float2 twiddle_n(const flo
 }
 
 // ---- pass 1: 16 columns of one transform; 16 * T1 threads ----------------------------------------------------
-// LDS: plane N1 x 16 floats, then W_1024 (8 KiB), then qtab 32 x 16 float2 (4 KiB)
+// in_x / ws_x: the transform's input matrix / its intermediate.  LDS: plane N1 x 16 floats, w1k = W_1024 (8 KiB, staged by
+// the caller), qtab 32 x 16 float2 (4 KiB)
 template <int L, int L1, bool REV>
-__global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const float2 *__restrict__ in, float2 *__restrict__ ws,
-                                                                          const float2 *__restrict__ tw_1024)
+__device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, uint32_t tile, float *plane, const float2 *w1k, float2 *qtab)
 {
-    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32, THREADS = kTile * T1, TILES = N2 / kTile;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
-    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
-    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(float));
-    float2 *qtab = w1k + 1024;
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32;
     const uint32_t t = threadIdx.x;
-    for (uint32_t i = t; i < 512; i += THREADS)
-        reinterpret_cast<float4 *>(w1k)[i] = reinterpret_cast<const float4 *>(tw_1024)[i];
-    const uint32_t tile = blockIdx.x % TILES;
-    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
     const uint32_t c = t & 15, u = t >> 4; // u < T1
     const uint32_t n2 = tile * kTile + c;
 
     // rows u + T1 k of column n2
-    const float2 *src_tile = in + xoff + tile * kTile;
+    const float2 *src_tile = in_x + tile * kTile;
     const uint32_t toff = (u * N2 + c) * 8u;
     float2 x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
         x[k] = nt_load(at(src_tile + (size_t)T1 * N2 * k, toff));
-    __syncthreads(); // w1k staged
+    __syncthreads(); // w1k staged (the two-launch kernels stage it while these loads are in flight)
 
     // the column part of the inter-pass twiddle: W_N^(n2 * j * 2^(L1-5)), j < 32; 32 / T1 entries per thread
 #pragma unroll
@@ -113,7 +105,7 @@ __global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const
     const uint32_t bu = brev_bits<L1 - 5>(u);
     const float2 pw = twiddle_n<L, REV>(w1k, n2 * bu);
     const float2 *const qcol = qtab + c;
-    float2 *dst_tile = ws + xoff + (size_t)tile * (N1 * kTile); // [tile][k1][c]
+    float2 *dst_tile = ws_x + (size_t)tile * (N1 * kTile); // [tile][k1][c]
     const uint32_t soff = (bu * 16 + c) * 8u;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
@@ -123,27 +115,36 @@ __global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const
         *at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff) = cmul(x[k], cmul(pw, qcol[16 * j]));
     }
 }
-
-// ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
-// LDS: plane 16 x N2 floats, then pass 2's thread twiddles [stage][lane] (5 x 32 float2)
-template <int L, int L1, bool REV>
-__global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const float2 *__restrict__ ws, float2 *__restrict__ out,
-                                                                              const float2 *__restrict__ tw_1024, float scale)
+__device__ __forceinline__ void stage_w1k2p(float2 *w1k, const float2 *tw_1024, uint32_t threads)
 {
-    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32, THREADS = kTile * T2, TILES = N1 / kTile;
+    for (uint32_t i = threadIdx.x; i < 512; i += threads)
+        reinterpret_cast<float4 *>(w1k)[i] = reinterpret_cast<const float4 *>(tw_1024)[i];
+}
+template <int L, int L1, bool REV>
+__global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const float2 *__restrict__ in, float2 *__restrict__ ws,
+                                                                          const float2 *__restrict__ tw_1024)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32, THREADS = kTile * T1, TILES = N2 / kTile;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
     float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
-    float2 *wrow = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(float));
-    const uint32_t t = threadIdx.x;
-    for (uint32_t i = t; i < 5 * 32; i += THREADS) // [stage][lane] = W_N2^(lane << stage) = W_1024^((lane 1024/N2) << stage)
-        wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : float2{ 1.0f, 0.0f };
-    const uint32_t tile = blockIdx.x % TILES;
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(float));
+    stage_w1k2p(w1k, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+    cols_tile2p<L, L1, REV>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024);
+}
+
+// ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
+// LDS: plane 16 x N2 floats; wrow = pass 2's thread twiddles [stage][lane] (5 x 32 float2, staged by the caller)
+template <int L, int L1, bool REV>
+__device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *wrow, float scale)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32;
+    const uint32_t t = threadIdx.x;
 
     // first register pass: T2 lanes run along a row; element n2 = ua + T2 k of row k1 = 16 tile + ra lives at
     // [(n2 >> 4)][k1][n2 & 15] of the intermediate
     const uint32_t ra = t / T2, ua = t % T2;
-    const float2 *src = ws + xoff + (size_t)tile * (kTile * kTile);
+    const float2 *src = ws_x + (size_t)tile * (kTile * kTile);
     float2 x[32];
     if constexpr (T2 == 32) {
         const uint32_t aoff = ((ua >> 4) * (N1 * kTile) + ra * 16 + (ua & 15)) * 8u;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(c
 
     // position 32 ub + k of row k1 holds X[k1 + N1 k2], k2 = (bit_reverse5(k) << (L2 - 5)) | bit_reverse(ub): 16 lanes write
     // 128 contiguous bytes (streaming store of the final result)
-    float2 *dst_tile = out + xoff + tile * kTile;
+    float2 *dst_tile = out_x + tile * kTile;
     const uint32_t bub = brev_bits<L2 - 5>(ub);
     const uint32_t boff = (bub * N1 + rb) * 8u;
 #pragma unroll
@@ -229,6 +230,25 @@ __global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(c
         }
         nt_store(at(dst_tile + (size_t)(__brev((uint32_t)k) >> 27) * ((size_t)N1 << (L2 - 5)), boff), v);
     }
+}
+// [stage][lane] = W_N2^(lane << stage) = W_1024^((lane 1024/N2) << stage)
+template <int L2> __device__ __forceinline__ void stage_wrow2p(float2 *wrow, const float2 *tw_1024, uint32_t threads)
+{
+    constexpr int N2 = 1 << L2, T2 = N2 / 32;
+    for (uint32_t i = threadIdx.x; i < 5 * 32; i += threads)
+        wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : float2{ 1.0f, 0.0f };
+}
+template <int L, int L1, bool REV>
+__global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const float2 *__restrict__ ws, float2 *__restrict__ out,
+                                                                              const float2 *__restrict__ tw_1024, float scale)
+{
+    constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32, THREADS = kTile * T2, TILES = N1 / kTile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
+    float2 *wrow = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(float));
+    stage_wrow2p<L2>(wrow, tw_1024, THREADS);
+    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+    rows_tile2p<L, L1, REV>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
 }
 
 template <int L, int L1, bool REV> int launch_pair(const fft_2pass_args &a, hipStream_t s)
@@ -260,21 +280,4 @@ template <int L, int L1> int launch_dir(const fft_2pass_args &a, hipStream_t s)
 } // namespace
 
 bool fft_2pass_supports(uint32_t n) { return n >= (1u << 16) && n <= (1u << 19) && sdsp_hip_is_power_of_2(n); }
-
-// both passes over one chunk of `count` transforms (the workspace holds `count` intermediates)
-int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream)
-{
-    if (a.count == 0)
-        return SDSP_HIP_OK;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (a.n) {
-    // N1 x N2: the longer factor goes to pass 2, whose exchange writes are conflict-free at N2 = 1024 only
-    case 1u << 16: return launch_dir<16, 8>(a, s);  //  256 x  256
-    case 1u << 17: return launch_dir<17, 8>(a, s);  //  256 x  512
-    case 1u << 18: return launch_dir<18, 9>(a, s);  //  512 x  512
-    case 1u << 19: return launch_dir<19, 9>(a, s);  //  512 x 1024
-    default: break;
-    }
-    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
-}
 } // namespace sdsp_hip
