@@ -280,4 +280,21 @@ template <int L, int L1> int launch_dir(const fft_2pass_args &a, hipStream_t s)
 } // namespace
 
 bool fft_2pass_supports(uint32_t n) { return n >= (1u << 16) && n <= (1u << 19) && sdsp_hip_is_power_of_2(n); }
+
+// both passes over one chunk of `count` transforms (the workspace holds `count` intermediates)
+int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream)
+{
+    if (a.count == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (a.n) {
+    // N1 x N2: the longer factor goes to pass 2, whose exchange writes are conflict-free at N2 = 1024 only
+    case 1u << 16: return launch_dir<16, 8>(a, s);  //  256 x  256
+    case 1u << 17: return launch_dir<17, 8>(a, s);  //  256 x  512
+    case 1u << 18: return launch_dir<18, 9>(a, s);  //  512 x  512
+    case 1u << 19: return launch_dir<19, 9>(a, s);  //  512 x 1024
+    default: break;
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
+}
 } // namespace sdsp_hip
