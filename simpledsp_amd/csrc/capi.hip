@@ -898,6 +898,8 @@ int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void
     return SDSP_HIP_OK;
 }
 
+static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint64_t batch, void *stream);
+
 int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint64_t batch, void *stream)
 {
     if (!p)
@@ -912,6 +914,18 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "convolve needs a complex plan (real-input plans are not supported)");
     if (int rc = use_device(p->device))
         return rc;
+    // launch pieces as in sdsp_hip_fft_exec (N <= 8192, single-launch kernels); the three-launch composition runs piece by piece
+    const bool single = (p->path == PATH_FFT4096 || p->path == PATH_REG || p->path == PATH_TILE) && p->n <= 8192;
+    const uint64_t row_bytes = (uint64_t)p->n * esize(p->precision);
+    const uint64_t piece = single ? piece_units(batch, row_bytes, p->n < 16 ? 4096 : 256) : batch;
+    for (uint64_t done = 0; done < batch; done += piece)
+        if (int rc = convolve_device(p, static_cast<char *>(data) + done * row_bytes, h, std::min(piece, batch - done), stream))
+            return rc;
+    return SDSP_HIP_OK;
+}
+
+static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint64_t batch, void *stream)
+{
     if (p->path == PATH_FFT4096 && p->variant == 0)
         return launch_fft4096_conv_f32(data, p->twt, h, batch, stream);
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode) {

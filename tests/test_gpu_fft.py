@@ -642,3 +642,30 @@ def test_one_wave_kernel_f64(sd, torch_cuda, oracle, radix, batch):
             assert bool((guard == 7.0 + 3.0j).all())
         assert plan.info.kernel.decode() == "sdsp_fft1024_wave"
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 700), (256, 4, "f32", 9000), (1024, 2, "f64", 600), (32768, 2, "f32", 40)])
+def test_convolve_launch_pieces_are_bit_identical(sd, torch_cuda, n, radix, precision, batch):
+    """sdsp_hip_fft_convolve goes out in the same launch pieces as sdsp_hip_fft_exec (fused kernels, and at N = 32768 the
+    three-launch composition, which is not split): the bits of the single launch."""
+    torch = torch_cuda
+    prec = sd.F64 if precision == "f64" else sd.F32
+    rdt = torch.float64 if precision == "f64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(n * 3 + batch)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device="cuda", dtype=rdt))
+    h = torch.view_as_complex(torch.randn((n, 2), generator=g, device="cuda", dtype=rdt))
+    old = sd.get_launch_piece_bytes()
+    try:
+        outs = []
+        for piece in (0, 1 << 20, 5 << 19):
+            sd.set_launch_piece_bytes(piece)
+            p = sd.FftPlan(n, radix, sd.forward_fft, prec, max_batch=batch)
+            d = x.clone()
+            p.convolve(d, h)
+            torch.cuda.synchronize()
+            outs.append(d)
+            p.close()
+        assert torch.equal(torch.view_as_real(outs[0]), torch.view_as_real(outs[1]))
+        assert torch.equal(torch.view_as_real(outs[0]), torch.view_as_real(outs[2]))
+    finally:
+        sd.set_launch_piece_bytes(old)
