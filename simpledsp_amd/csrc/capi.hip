@@ -940,6 +940,8 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
         a.nontemporal = 1;
         a.real_mode = 3; // fused convolution: one kernel, h travels in tw2
         a.tw2 = h;
+        if (fft_wave_supports(p->n, p->radix)) // N = 1024: both transforms in one wave's registers (fft_wave.hip)
+            return launch_fft_wave_f32(a, stream);
         return launch_fft_reg_f32(a, stream);
     }
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0 && !p->real_mode) { // f64, N = 16 .. 8192

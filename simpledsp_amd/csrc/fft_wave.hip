@@ -80,9 +80,15 @@ template <int SH> __device__ __forceinline__ uint32_t xterm_dev(uint32_t h)
 }
 
 // WAVES: transforms (= waves) per workgroup: 4 in f32 (32 KiB of LDS), 2 in f64 (32 KiB)
-template <typename C, typename S, int RADIX, bool REV, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ data, const C *__restrict__ tw, uint64_t batch, S scale)
+// CONV (forward plans): data <- IFFT(FFT(data) .* h) in one kernel (what a reference user writes as
+// fft_radix4(x); x[k] *= H[k]; fft_radix4<reverse_fft>(x)): the forward result X[t + 64 reversed(i)] in register i is the
+// input layout of the transform's own first pass, so after the per-bin multiply (h: natural order, 8 KiB, from L2) the
+// reverse transform runs on the same registers and LDS region with the conjugated thread twiddles; 1/N at the end.
+template <typename C, typename S, int RADIX, bool REV, int WAVES, bool CONV = false>
+__global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ data, const C *__restrict__ tw, uint64_t batch, S scale,
+                                                                const C *__restrict__ h = nullptr)
 {
+    static_assert(!(CONV && REV), "the fused convolution belongs to forward plans");
     constexpr int SH = sizeof(C) == 8 ? 5 : 4;
     __shared__ __attribute__((aligned(16))) C lds_all[WAVES][1024];
     const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -99,30 +105,40 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
     for (int k = 0; k < 16; k++)
         x[k] = gload(src + 64 * k);
 
-    auto run_pass = [&](auto pass_tag) {
+    // RV: direction of this pass (differs from REV only in the second half of the fused convolution, which runs the reverse
+    // transform with the conjugates of the forward thread twiddles)
+    auto run_pass = [&](auto pass_tag, auto rev_tag) {
         constexpr int I = decltype(pass_tag)::value;
+        constexpr bool RV = decltype(rev_tag)::value;
+        auto twc = [&](int v) {
+            C w = twl(I, v);
+            if constexpr (RV != REV)
+                w.y = -w.y;
+            return w;
+        };
         if constexpr (RADIX == 2) {
             C w[4];
             if constexpr (I < 2) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    w[j] = twl(I, j);
+                    w[j] = twc(j);
             }
-            passes::r2_pass<REV, (I < 2), (I == 2 ? 2 : 0)>::run(x, w);
+            passes::r2_pass<RV, (I < 2), (I == 2 ? 2 : 0)>::run(x, w);
         } else {
             C w1[3], w2[3];
             if constexpr (I < 2) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
-                    w1[q] = twl(I, q);
-                    w2[q] = twl(I, q + 3);
+                    w1[q] = twc(q);
+                    w2[q] = twc(q + 3);
                 }
             }
-            passes::r4_pass<REV, (I < 2), (I < 2)>(x, w1, w2);
+            passes::r4_pass<RV, (I < 2), (I < 2)>(x, w1, w2);
         }
     };
-
-    run_pass(std::integral_constant<int, 0>{});
+    const uint32_t w = RADIX == 2 ? (__brev(t) >> 26) : (((t & 3u) << 4) | (t & 12u) | (t >> 4));
+    auto transform = [&](auto rev_tag) {
+    run_pass(std::integral_constant<int, 0>{}, rev_tag);
 
     // ---- exchange A -> B.  A: p = t + 64 k, p >> SH = (t >> SH) | (k << (6 - SH))
     {
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
             x[j] = lds[a ^ ((4u * j) ^ xterm<SH>((uint32_t)j >> (SH - 2)))];
     }
 
-    run_pass(std::integral_constant<int, 1>{});
+    run_pass(std::integral_constant<int, 1>{}, rev_tag);
 
     // ---- exchange B -> C (pass B's slots are written by the thread that read them)
     {
@@ -153,7 +169,6 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
             lds[a ^ ((4u * j) ^ xterm<SH>((uint32_t)j >> (SH - 2)))] = x[j];
     }
     // C: p = 16 w + i, p >> SH = w >> (SH - 4); w = reversed(t) so that the outputs land at t + 64 * reversed(i)
-    const uint32_t w = RADIX == 2 ? (__brev(t) >> 26) : (((t & 3u) << 4) | (t & 12u) | (t >> 4));
     {
         uint32_t a = (16u * w) ^ xterm_dev<SH>(w >> (SH - 4));
         asm volatile("" : "+v"(a));
@@ -162,13 +177,30 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
             x[i] = lds[a ^ (uint32_t)i];
     }
 
-    run_pass(std::integral_constant<int, 2>{});
+    run_pass(std::integral_constant<int, 2>{}, rev_tag);
+    };
+    transform(std::integral_constant<bool, REV>{});
+
+    if constexpr (CONV) {
+        // x[i] = X[t + 64 row(i)]: multiply by h there and renumber so that register row(i) is element t + 64 row(i) -- the
+        // first pass's input layout
+        C z[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = RADIX == 2 ? (int)(__brev((uint32_t)i) >> 28) : 4 * (i & 3) + (i >> 2);
+            z[row] = passes::cmul(x[i], h[t + 64 * row]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            x[i] = z[i];
+        transform(std::integral_constant<bool, true>{});
+    }
 
     C *dst = data + f * 1024 + t;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         C v = x[i];
-        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+        if constexpr (REV || CONV) { // reverse_fft::ScaleValues, fft.h:128-132
             v.x *= scale;
             v.y *= scale;
         }
@@ -177,14 +209,15 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
     }
 }
 
-template <typename C, typename S, int RADIX, bool REV> int launch_t(const fft_reg_args &a, S scale, hipStream_t s)
+template <typename C, typename S, int RADIX, bool REV, bool CONV = false> int launch_t(const fft_reg_args &a, S scale, hipStream_t s)
 {
     constexpr int WAVES = sizeof(C) == 8 ? 4 : 2;
     const uint64_t blocks = (a.batch + WAVES - 1) / WAVES;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL((sdsp_fft1024_wave<C, S, RADIX, REV, WAVES>), dim3((uint32_t)blocks), dim3(64 * WAVES), 0, s,
-                       reinterpret_cast<C *>(a.data), reinterpret_cast<const C *>(a.tw), a.batch, scale);
+    hipLaunchKernelGGL((sdsp_fft1024_wave<C, S, RADIX, REV, WAVES, CONV>), dim3((uint32_t)blocks), dim3(64 * WAVES), 0, s,
+                       reinterpret_cast<C *>(a.data), reinterpret_cast<const C *>(a.tw), a.batch, scale,
+                       reinterpret_cast<const C *>(a.tw2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_wave launch: ") + hipGetErrorString(e));
@@ -193,6 +226,11 @@ template <typename C, typename S, int RADIX, bool REV> int launch_t(const fft_re
 
 template <typename C, typename S> int launch_c(const fft_reg_args &a, S scale, hipStream_t s)
 {
+    if (a.real_mode == 3) { // fused convolution: forward plan, tw2 = h
+        if (a.reverse || !a.tw2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fused convolution needs a forward plan and h");
+        return a.radix == 2 ? launch_t<C, S, 2, false, true>(a, scale, s) : launch_t<C, S, 4, false, true>(a, scale, s);
+    }
     if (a.radix == 2)
         return a.reverse ? launch_t<C, S, 2, true>(a, scale, s) : launch_t<C, S, 2, false>(a, scale, s);
     return a.reverse ? launch_t<C, S, 4, true>(a, scale, s) : launch_t<C, S, 4, false>(a, scale, s);

@@ -410,7 +410,7 @@ def test_fft1m_schedules_agree(sd, torch_cuda, oracle):
 
 @pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
                                                      (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2),
-                                                     (16, 2, "f32", 300), (64, 4, "f32", 70), (1024, 2, "f32", 9),
+                                                     (16, 2, "f32", 300), (64, 4, "f32", 70), (1024, 2, "f32", 9), (1024, 4, "f32", 1030),
                                                      (2048, 2, "f32", 3), (16384, 4, "f32", 2), (8192, 2, "f32", 2),
                                                      (64, 4, "f64", 70), (4096, 4, "f64", 3), (8192, 2, "f64", 2), (16384, 2, "f64", 2)])
 def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
