@@ -147,6 +147,26 @@ int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int rad
     return upload_twiddles(tab, precision, dev); // rounds to the plan precision exactly like the row itself
 }
 
+// Thread-twiddle table of fft_wave.hip's N = 256 / 512 / 2048 kernels: [global stage g][lane t] = W^((t mod s_i) << g) for
+// the stages of pass i < last (P = n / 64 points per lane, log2 P stages per pass, s_i = n >> (log2 P (i + 1))); the last
+// pass has no thread twiddles.
+int upload_thread_twiddles_wave(const std::vector<double> &w, uint32_t n, void **dev)
+{
+    const uint32_t L = sdsp_hip_log2(n), LP = L - 6, NP = (L + LP - 1) / LP;
+    std::vector<double> tab((size_t)(NP - 1) * LP * 64 * 2, 0.0);
+    for (uint32_t i = 0; i + 1 < NP; i++) {
+        const uint32_t sg = n >> (LP * (i + 1));
+        for (uint32_t s = 0; s < LP; s++)
+            for (uint32_t t = 0; t < 64; t++) {
+                const size_t idx = (size_t)(t % sg) << (i * LP + s);
+                const size_t o = ((size_t)(i * LP + s) * 64 + t) * 2;
+                tab[o] = w[2 * idx];
+                tab[o + 1] = w[2 * idx + 1];
+            }
+    }
+    return upload_twiddles(tab, SDSP_HIP_F32, dev);
+}
+
 // Thread-twiddle table of fft_big.hip: [pass (A, B)][stage s < 5][thread t < N/32] = W^(t << s) for pass A,
 // W^((32 v) << s), v = t mod (N/1024), for pass B.
 int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **dev)
@@ -207,6 +227,7 @@ struct sdsp_hip_fft_plan {
     void *twt = nullptr;           // tuned N = 4096 f32 kernels: thread-twiddle table
     void *twt_reg = nullptr;       // register-pass family (f32): thread-twiddle table
     void *twt_big = nullptr;       // fft_big.hip: thread-twiddle table
+    void *twt_wave = nullptr;      // fft_wave.hip, N = 256 / 512 / 2048 radix 2: [stage][lane] table
     void *twt_mix = nullptr;       // fft_mix.hip (N = 8192 / 16384): the sub-transforms' thread-twiddle table ...
     void *tw_lead = nullptr;       // ... and the leading stage's thread twiddles W_N^(q t)
     uint32_t n1 = 0, n2 = 0;       // four-step split
@@ -357,6 +378,12 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.tw2 = p->tw2;
         if (variant == 0 && !p->real_mode && fft_wave_supports(p->n, p->radix)) // N = 1024: one transform per wave
             return launch_fft_wave_f32(a, stream);
+        // N = 256 / 2048 radix 2: 1024 points (or one transform) per wave.  At N = 512 the register-pass kernel measures
+        // faster for the plain transform (74.2-74.8 % against 72.1-72.8 %); the fused convolution uses the wave kernel there too
+        if (variant == 0 && !p->real_mode && p->twt_wave && p->n != 512) {
+            a.tw = p->twt_wave;
+            return launch_fft_wave2_f32(a, stream);
+        }
         return launch_fft_reg_f32(a, stream);
     }
 
@@ -686,6 +713,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
             rc = upload_thread_twiddles_big(w, n, &p->twt_big);
+        if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
+            rc = upload_thread_twiddles_wave(w, n, &p->twt_wave);
         if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
             rc = upload_thread_twiddles_mix(w, n, &p->twt_mix, &p->tw_lead);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);
@@ -802,6 +831,7 @@ int sdsp_hip_fft_plan_destroy(sdsp_hip_fft_plan *p)
         (void)hipFree(p->twt);
         (void)hipFree(p->twt_reg);
         (void)hipFree(p->twt_big);
+        (void)hipFree(p->twt_wave);
         (void)hipFree(p->twt_mix);
         (void)hipFree(p->tw_lead);
         (void)hipFree(p->tw1024);
@@ -928,7 +958,9 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
 {
     if (p->path == PATH_FFT4096 && p->variant == 0)
         return launch_fft4096_conv_f32(data, p->twt, h, batch, stream);
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode) {
+    // variant 0: the fused kernel of the size; variant 2: the register-pass family's fused MODE 3 where a one-wave kernel
+    // is the default (A/B and cross-check); any other variant: three launches
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (p->variant == 0 || p->variant == 2) && !p->real_mode) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;
@@ -940,8 +972,12 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
         a.nontemporal = 1;
         a.real_mode = 3; // fused convolution: one kernel, h travels in tw2
         a.tw2 = h;
-        if (fft_wave_supports(p->n, p->radix)) // N = 1024: both transforms in one wave's registers (fft_wave.hip)
+        if (p->variant == 0 && fft_wave_supports(p->n, p->radix)) // N = 1024: both transforms in one wave's registers (fft_wave.hip)
             return launch_fft_wave_f32(a, stream);
+        if (p->variant == 0 && p->twt_wave) { // N = 256 / 512 / 2048 radix 2
+            a.tw = p->twt_wave;
+            return launch_fft_wave2_f32(a, stream);
+        }
         return launch_fft_reg_f32(a, stream);
     }
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0 && !p->real_mode) { // f64, N = 16 .. 8192
@@ -1008,6 +1044,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
     if (p->path == PATH_REG && p->variant == (p->precision == SDSP_HIP_F64 ? 1 : 0) && !p->real_mode && fft_wave_supports(p->n, p->radix))
         name = "sdsp_fft1024_wave";
+    if (p->path == PATH_REG && p->variant == 0 && !p->real_mode && p->twt_wave && p->n != 512)
+        name = "sdsp_fft_wave_f32";
     if (big)
         name = "sdsp_fft_big_kernel";
     if (mix_size && p->variant == 0)

@@ -26,6 +26,7 @@
 // distinct 8-byte bank pairs in each half-wave; f64 (ds_*_b128, SH = 4): 16 distinct 16-byte bank quads in each quarter-wave.
 #include <hip/hip_runtime.h>
 
+#include "fft32.h"
 #include "fft_passes.h"
 #include "sdsp_hip_internal.h"
 
@@ -209,6 +210,212 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same idea for N = 256, 512 and 2048 (radix-2 stages, f32): a wave owns 1024 consecutive points (N <= 512: 4 or 2 whole
+// transforms) or one transform of 2048, P = N / 64 points of each transform per lane.  Loads and stores are the N = 1024
+// kernel's (register j = element t + 64 j of the wave's block: 512 contiguous bytes per instruction); a transform's log2 N
+// stages run as passes of log2 P stages on the lane's P points:
+//   pass i < last   positions b (s_i P) + v + s_i k,  s_i = N >> (log2 P (i + 1)),  v = t mod s_i,  b = t / s_i; thread
+//                   twiddle of global stage g: W_N^(v << g), from the plan's [stage][lane] table (capi.hip:
+//                   upload_thread_twiddles_wave), times compile-time W_P constants
+//   last pass       the remaining stages on the P contiguous positions P w + k, w = bit_reverse6(t): outputs X[t + 64 rev(k)]
+// with one exchange through the wave's own LDS between passes (in order, no barrier).  Slot map: p ^ X(p >> 5), X linear
+// over GF(2), rows found by search per size (tools/model_fft_wave.py): every access pattern conflict-free per half-wave.
+template <int L> struct rows2;
+template <> struct rows2<8> {
+    static constexpr uint32_t r[6] = { 31, 20, 10, 0, 0, 0 };
+};
+template <> struct rows2<9> {
+    static constexpr uint32_t r[6] = { 23, 31, 20, 26, 0, 0 };
+};
+template <> struct rows2<11> {
+    static constexpr uint32_t r[6] = { 9, 15, 24, 2, 5, 6 };
+};
+template <int L> constexpr uint32_t xterm2(uint32_t h)
+{
+    uint32_t x = 0;
+    for (int b = 0; b < L - 5; b++)
+        if ((h >> b) & 1)
+            x ^= rows2<L>::r[b];
+    return x;
+}
+template <int L> __device__ __forceinline__ uint32_t xterm2_dev(uint32_t h)
+{
+    uint32_t x = 0;
+#pragma unroll
+    for (int b = 0; b < L - 5; b++)
+        x ^= ((h >> b) & 1) ? rows2<L>::r[b] : 0u;
+    return x;
+}
+
+// stages S0 .. log2(P) - 1 of the P-point radix-2 DIF network on x[0 .. P) (fft.h:286-291 in decimation-in-frequency
+// form); the factor the lower output owes = thread twiddle w[s] (when TW) x the constant W_P^((k mod h) << s)
+template <bool REV, bool TW, int P, int S0> __device__ __forceinline__ void dif_p(float2 *x, const float2 *w)
+{
+    constexpr int LP = P == 4 ? 2 : P == 8 ? 3 : P == 16 ? 4 : 5;
+#pragma unroll
+    for (int s = S0; s < LP; s++) {
+        const int h = P >> (s + 1);
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            if ((k & h) != 0)
+                continue;
+            const float2 a = x[k], b = x[k + h];
+            x[k] = float2{ a.x + b.x, a.y + b.y };
+            float2 d = float2{ a.x - b.x, a.y - b.y };
+            const int e = ((k & (h - 1)) << s) * (32 / P); // W_32 exponent, 0 .. 15
+            if (e == 8) {
+                d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x };
+            } else if (e != 0) {
+                const float cr = fft32::kC32[e], ci = REV ? fft32::kS32[e] : -fft32::kS32[e];
+                d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
+            }
+            if constexpr (TW)
+                d = passes::cmul(d, w[s]);
+            x[k + h] = d;
+        }
+    }
+}
+
+template <int L, bool REV, bool CONV>
+__global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ data, const float2 *__restrict__ tw, uint64_t batch, float scale,
+                                                         const float2 *__restrict__ h)
+{
+    static_assert(!(CONV && REV), "the fused convolution belongs to forward plans");
+    constexpr int LP = L - 6, P = 1 << LP, N = 1 << L, NP = (L + LP - 1) / LP, REM = L - LP * (NP - 1);
+    constexpr int TPW = P >= 16 ? 1 : 16 / P, R = P * TPW; // transforms per wave, registers per lane
+    __shared__ __attribute__((aligned(16))) float2 lds_all[4][64 * R];
+    const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float2 *lds = lds_all[wave];
+    const uint64_t f0 = (static_cast<uint64_t>(blockIdx.x) * 4 + wave) * TPW; // the wave's first transform
+    if (f0 >= batch)
+        return; // wave-uniform; the kernel has no barrier
+    const uint32_t live = batch - f0 >= (uint64_t)TPW ? (uint32_t)TPW : (uint32_t)(batch - f0);
+
+    float2 x[R];
+    float2 *const blk = data + f0 * N + t;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        x[j] = float2{ 0.0f, 0.0f };
+        if (TPW == 1 || (uint32_t)(j / P) < live)
+            x[j] = gload(blk + 64 * j);
+    }
+
+    const uint32_t w = __brev(t) >> 26;
+    auto transform = [&](auto rev_tag) {
+        constexpr bool RV = decltype(rev_tag)::value;
+        auto run_pass = [&](auto pass_tag) {
+            constexpr int I = decltype(pass_tag)::value;
+            constexpr bool last = I == NP - 1;
+            float2 wt[LP];
+            if constexpr (!last) {
+#pragma unroll
+                for (int s = 0; s < LP; s++) {
+                    wt[s] = tw[(I * LP + s) * 64 + t];
+                    if constexpr (RV != REV)
+                        wt[s].y = -wt[s].y;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < TPW; g++)
+                dif_p<RV, !last, P, (last ? LP - REM : 0)>(x + g * P, wt);
+        };
+        // slot address of register (g, k) in pass I's layout = g N + (A_I(t) ^ B_I(k))
+        auto a_of = [&](auto pass_tag) -> uint32_t {
+            constexpr int I = decltype(pass_tag)::value;
+            if constexpr (I == NP - 1) {
+                return (P * w) ^ xterm2_dev<L>((P * w) >> 5);
+            } else {
+                constexpr uint32_t sg = (uint32_t)N >> (LP * (I + 1));
+                const uint32_t base = (t / sg) * (sg * P) + (t % sg);
+                return base ^ xterm2_dev<L>(base >> 5);
+            }
+        };
+        auto exchange = [&](auto from_tag) { // pass I's layout -> pass I + 1's
+            constexpr int I = decltype(from_tag)::value;
+            constexpr uint32_t s_from = I == NP - 1 ? 1u : (uint32_t)N >> (LP * (I + 1));
+            constexpr uint32_t s_to = I + 1 == NP - 1 ? 1u : (uint32_t)N >> (LP * (I + 2));
+            {
+                uint32_t a = a_of(from_tag);
+                asm volatile("" : "+v"(a)); // one v_xor per access instead of R live addresses
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const uint32_t k = (uint32_t)(j % P), g = (uint32_t)(j / P);
+                    lds[g * N + (a ^ ((s_from * k) ^ xterm2<L>((s_from * k) >> 5)))] = x[j];
+                }
+            }
+            {
+                uint32_t a = a_of(std::integral_constant<int, I + 1>{});
+                asm volatile("" : "+v"(a));
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const uint32_t k = (uint32_t)(j % P), g = (uint32_t)(j / P);
+                    x[j] = lds[g * N + (a ^ ((s_to * k) ^ xterm2<L>((s_to * k) >> 5)))];
+                }
+            }
+        };
+        run_pass(std::integral_constant<int, 0>{});
+        exchange(std::integral_constant<int, 0>{});
+        run_pass(std::integral_constant<int, 1>{});
+        exchange(std::integral_constant<int, 1>{});
+        run_pass(std::integral_constant<int, 2>{});
+        if constexpr (NP > 3) {
+            exchange(std::integral_constant<int, 2>{});
+            run_pass(std::integral_constant<int, 3>{});
+        }
+    };
+    transform(std::integral_constant<bool, REV>{});
+
+    if constexpr (CONV) {
+        // register (g, k) holds X_g[t + 64 rev(k)]: multiply by h there, renumber to the first pass's input layout
+        float2 z[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int k = j % P, g = j / P, row = (int)(__brev((uint32_t)k) >> (32 - LP));
+            z[g * P + row] = passes::cmul(x[j], h[t + 64 * row]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            x[j] = z[j];
+        transform(std::integral_constant<bool, true>{});
+    }
+
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int k = j % P, g = j / P, row = (int)(__brev((uint32_t)k) >> (32 - LP));
+        float2 v = x[j];
+        if constexpr (REV || CONV) { // reverse_fft::ScaleValues, fft.h:128-132
+            v.x *= scale;
+            v.y *= scale;
+        }
+        if (TPW == 1 || (uint32_t)g < live)
+            gstore(blk + 64 * (g * P + row), v);
+    }
+}
+
+template <int L, bool REV, bool CONV> int launch_w2(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr int P = 1 << (L - 6), TPW = P >= 16 ? 1 : 16 / P;
+    const uint64_t waves = (a.batch + TPW - 1) / TPW, blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL((sdsp_fft_wave_f32<L, REV, CONV>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
+                       reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale, reinterpret_cast<const float2 *>(a.tw2));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_wave launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+template <int L> int launch_w2_mode(const fft_reg_args &a, hipStream_t s)
+{
+    if (a.real_mode == 3) {
+        if (a.reverse || !a.tw2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fused convolution needs a forward plan and h");
+        return launch_w2<L, false, true>(a, s);
+    }
+    return a.reverse ? launch_w2<L, true, false>(a, s) : launch_w2<L, false, false>(a, s);
+}
+
 template <typename C, typename S, int RADIX, bool REV, bool CONV = false> int launch_t(const fft_reg_args &a, S scale, hipStream_t s)
 {
     constexpr int WAVES = sizeof(C) == 8 ? 4 : 2;
@@ -240,6 +447,28 @@ template <typename C, typename S> int launch_c(const fft_reg_args &a, S scale, h
 bool fft_wave_supports(uint32_t n, int radix)
 {
     return n == 1024 && (radix == 2 || radix == 4);
+}
+
+// N = 256 / 512 / 2048, radix-2 stages, f32: a.tw = the plan's [stage][lane] table (capi.hip: upload_thread_twiddles_wave)
+bool fft_wave2_supports(uint32_t n, int radix)
+{
+    return radix == 2 && (n == 256 || n == 512 || n == 2048);
+}
+
+int launch_fft_wave2_f32(const fft_reg_args &a, void *stream)
+{
+    if (a.batch == 0)
+        return SDSP_HIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a.radix == 2) {
+        switch (a.n) {
+        case 256: return launch_w2_mode<8>(a, s);
+        case 512: return launch_w2_mode<9>(a, s);
+        case 2048: return launch_w2_mode<11>(a, s);
+        default: break;
+        }
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the one-wave kernels");
 }
 
 // a.tw: the plan's register-pass thread-twiddle table (twt_reg), in the plan's precision

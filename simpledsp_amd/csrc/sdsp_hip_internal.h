@@ -97,6 +97,9 @@ int launch_fft_reg_f64(const fft_reg_args &a, void *stream);
 bool fft_wave_supports(uint32_t n, int radix);
 int launch_fft_wave_f32(const fft_reg_args &a, void *stream);
 int launch_fft_wave_f64(const fft_reg_args &a, void *stream); // scale_d
+// N = 256 / 512 / 2048 f32, radix-2 stages: 1024 points (or one transform of 2048) per wave; a.tw = twt_wave
+bool fft_wave2_supports(uint32_t n, int radix);
+int launch_fft_wave2_f32(const fft_reg_args &a, void *stream);
 bool fft_big_supports(uint32_t n, int radix);
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 

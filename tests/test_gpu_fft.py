@@ -118,7 +118,7 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
 
 
 @pytest.mark.parametrize("n,radix,batch", [(16, 2, 1), (16, 4, 300), (32, 2, 129), (64, 4, 1000), (128, 2, 33), (256, 4, 17),
-                                           (512, 2, 9), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
+                                           (512, 2, 9), (512, 2, 1031), (256, 2, 4098), (256, 2, 3), (2048, 2, 130), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
                                            (8192, 2, 3), (16384, 2, 2), (16384, 4, 3)])
 def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
     # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
@@ -130,9 +130,11 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
         big = n >= 8192  # radix 2: registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
         mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
+        wave2 = radix == 2 and n in (256, 2048)  # csrc/fft_wave.hip: 1024 points (or one transform of 2048) per wave
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
                                              "sdsp_fft_big_kernel" if big else
-                                             "sdsp_fft1024_wave" if n == 1024 else "sdsp_fft_reg_kernel")  # csrc/fft_wave.hip: one transform per wave
+                                             "sdsp_fft1024_wave" if n == 1024 else  # csrc/fft_wave.hip: one transform per wave
+                                             "sdsp_fft_wave_f32" if wave2 else "sdsp_fft_reg_kernel")
         outs = []
         # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel (, the size's tuned kernel)
         # N = 1024: variant 0 is the one-wave kernel, which runs the register-pass family's arithmetic: the same bits
@@ -145,7 +147,9 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
             outs.append(d.cpu().numpy())
             assert rel_max_err(outs[-1], want) < TOL32, (n, radix, rev, variant, rel_max_err(outs[-1], want))
             assert bool((guard == 7.0 + 3.0j).all())
-        if not mix:
+        if wave2:  # passes of log2(N / 64) stages instead of four: another split of the same twiddles, not the same roundings
+            assert rel_max_err(outs[0], outs[1]) < 1e-6
+        elif not mix:
             assert np.array_equal(outs[0], outs[1])
 
 
@@ -411,6 +415,7 @@ def test_fft1m_schedules_agree(sd, torch_cuda, oracle):
 @pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
                                                      (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2),
                                                      (16, 2, "f32", 300), (64, 4, "f32", 70), (1024, 2, "f32", 9), (1024, 4, "f32", 1030),
+                                                     (256, 2, "f32", 1027), (512, 2, "f32", 77), (2048, 2, "f32", 35),
                                                      (2048, 2, "f32", 3), (16384, 4, "f32", 2), (8192, 2, "f32", 2),
                                                      (64, 4, "f64", 70), (4096, 4, "f64", 3), (8192, 2, "f64", 2), (16384, 2, "f64", 2)])
 def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
@@ -428,15 +433,16 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
     tol = 2e-6 if prec == sd.F32 else 8 * n * EPS64  # two transforms and a product
     outs = []
     fused = n <= (16384 if prec == sd.F32 else 8192)
-    for variant in ((0, 1) if fused else (0,)):
+    two_fused = prec == sd.F32 and (n == 1024 or (radix == 2 and n in (256, 512, 2048)))  # one-wave kernel + the register-pass MODE 3 (variant 2)
+    for variant in ((0, 1, 2) if two_fused else (0, 1) if fused else (0,)):
         plan.set_variant(variant)  # f32 n <= 16384, f64 n <= 8192: 0 = fused single kernel, 1 = three launches
         d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
         plan.convolve(d, hd)
         torch.cuda.synchronize()
         outs.append(d.cpu().numpy())
         assert rel_max_err(outs[-1], want) < tol, (variant, rel_max_err(outs[-1], want))
-    if len(outs) == 2:
-        assert rel_max_err(outs[0], outs[1]) < (1e-6 if prec == sd.F32 else tol)
+    for other in outs[1:]:
+        assert rel_max_err(outs[0], other) < (1e-6 if prec == sd.F32 else tol)
     with pytest.raises(sd.SdspHipError):
         sd.FftPlan(n, radix, sd.reverse_fft, prec).convolve(torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda())
 

@@ -44,7 +44,41 @@ def conflict_free(rows, pats, sh=5):
     return all(len({slot(rows, p, sh) & (lanes - 1) for p in pat[h:h + lanes]}) == lanes for pat in pats for h in range(0, 64, lanes))
 
 
+# ---- N = 256 / 512 / 2048 (sdsp_fft_wave_f32): P = N / 64 points per lane, passes of log2 P radix-2 stages
+ROWS2 = {8: [31, 20, 10], 9: [23, 31, 20, 26], 11: [9, 15, 24, 2, 5, 6]}  # csrc/fft_wave.hip: rows2<L>
+
+
+def patterns2(L):
+    LP = L - 6
+    P, N, NP = 1 << LP, 1 << L, -(-L // LP)
+    pats = []
+    for i in range(NP - 1):  # pass i: positions b (s P) + v + s k
+        sg = N >> (LP * (i + 1))
+        pats += [[(t // sg) * (sg * P) + (t % sg) + sg * k for t in range(64)] for k in range(P)]
+    pats += [[P * brev6(t) + k for t in range(64)] for k in range(P)]  # last pass: P contiguous positions of block w
+    return pats
+
+
+def slot2(rows, p, L):
+    x = 0
+    for b in range(L - 5):
+        if (p >> (5 + b)) & 1:
+            x ^= rows[b]
+    return p ^ x
+
+
+def conflict_free2(rows, pats, L):
+    return all(len({slot2(rows, p, L) & 31 for p in pat[h:h + 32]}) == 32 for pat in pats for h in (0, 32))
+
+
 if __name__ == "__main__":
+    for L, rows in ROWS2.items():
+        pats = patterns2(L)
+        assert all(sorted(p for pat in pats[i * (1 << (L - 6)):(i + 1) * (1 << (L - 6))] for p in pat) == list(range(1 << L))
+                   for i in range(len(pats) >> (L - 6))), "a pass layout does not cover the transform"
+        assert conflict_free2(rows, pats, L), f"rows2<{L}> are not conflict free"
+        assert sorted(slot2(rows, p, L) for p in range(1 << L)) == list(range(1 << L))
+        print(f"rows2<{L}> = {rows}: {len(pats)} access patterns conflict free")
     p2, p4 = patterns(2), patterns(4)
     assert conflict_free(K_ROW, p2) and conflict_free(K_ROW, p4), "the compiled rows are not conflict free"
     ident = [0, 0, 0, 0, 0]
