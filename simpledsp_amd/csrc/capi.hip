@@ -376,11 +376,13 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.nontemporal = variant != 1 || mix_size; // 1: default cache policy (N < 8192)
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
-        if (variant == 0 && !p->real_mode && fft_wave_supports(p->n, p->radix)) // N = 1024: one transform per wave
+        // one-wave kernels (fft_wave.hip), where they measured faster than this family.  Complex transform: N = 1024 (either
+        // stage type), N = 256 / 2048 radix 2 (N = 512: 72.1-72.8 % against 74.2-74.8 % here).  Real-input plans (split /
+        // merge by ds_bpermute): n_real = 512 / 1024 / 2048 radix 2: 71.9 / 70.5 / 67.3 % against 70.6 / 66.5 / 66.2 %
+        // (radix 4 at 2048: 65.5 / 65.6; n_real = 4096: 59.8 against 64.5 %, 174 VGPRs -- both stay here)
+        if (variant == 0 && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
             return launch_fft_wave_f32(a, stream);
-        // N = 256 / 2048 radix 2: 1024 points (or one transform) per wave.  At N = 512 the register-pass kernel measures
-        // faster for the plain transform (74.2-74.8 % against 72.1-72.8 %); the fused convolution uses the wave kernel there too
-        if (variant == 0 && !p->real_mode && p->twt_wave && p->n != 512) {
+        if (variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512)) {
             a.tw = p->twt_wave;
             return launch_fft_wave2_f32(a, stream);
         }
@@ -1042,9 +1044,10 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     if (p->path == PATH_REG && p->variant < 3)
         name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
                p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
-    if (p->path == PATH_REG && p->variant == (p->precision == SDSP_HIP_F64 ? 1 : 0) && !p->real_mode && fft_wave_supports(p->n, p->radix))
+    if (p->path == PATH_REG && p->variant == (p->precision == SDSP_HIP_F64 ? 1 : 0) &&
+        (!p->real_mode || (p->precision == SDSP_HIP_F32 && p->radix == 2)) && fft_wave_supports(p->n, p->radix))
         name = "sdsp_fft1024_wave";
-    if (p->path == PATH_REG && p->variant == 0 && !p->real_mode && p->twt_wave && p->n != 512)
+    if (p->path == PATH_REG && p->variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
         name = "sdsp_fft_wave_f32";
     if (big)
         name = "sdsp_fft_big_kernel";

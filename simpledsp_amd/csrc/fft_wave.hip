@@ -57,6 +57,41 @@ __device__ __forceinline__ void gstore(double2 *p, double2 a)
     __builtin_nontemporal_store(v2d_t{ a.x, a.y }, reinterpret_cast<v2d_t *>(p));
 }
 
+// Real-input packing (fft_reg.hip MODE 1 / 2) inside a wave.  The buffer holds 2N real samples per
+// transform, read as N = 64 P complex z[m] = x[2m] + i x[2m+1]; a lane owns the elements k = t + 64 r, r < P, of a
+// transform.  The partner element (N - k) mod N of the split / merge lives in lane (64 - t) mod 64, row P - 1 - r -- for
+// lane 0 in the lane itself, row (P - r) mod P -- so it arrives by ONE ds_bpermute per word instead of an LDS pass with barriers.
+//   SPLIT (forward, after the transform):  X[k] = E + T, E = (Z[k] + conj Z[N-k]) / 2, T = -i W_2N^k (Z[k] - conj Z[N-k]) / 2;
+//                                          element 0 is stored as (X[0], X[N]), both real
+//   MERGE (inverse, before the transform): Z[k] = E + i conj(W_2N^k) (X[k] - conj X[N-k]) / 2 (tw2 is reverse-folded);
+//                                          element 0 = ((X[0] + X[N]) / 2, (X[0] - X[N]) / 2)
+// reg_of(r): the register that holds row r (the transform's output order for SPLIT, natural order for MERGE).
+template <int P, bool MERGE, typename RegOf>
+__device__ __forceinline__ void real_pack_stage(float2 *x, uint32_t t, const float2 *__restrict__ tw2, RegOf reg_of)
+{
+    const int src = (int)((64u - t) & 63u);
+    float2 y[P];
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        const int j = reg_of(r), jp = reg_of(P - 1 - r), j0 = reg_of((P - r) % P);
+        const float2 za = x[j];
+        const float2 other = float2{ __shfl(x[jp].x, src), __shfl(x[jp].y, src) };
+        const float2 zb = t == 0 ? x[j0] : other;
+        const float2 w = tw2[t + 64 * r];
+        const float2 e = float2{ 0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y) }; // (za + conj zb) / 2
+        const float2 d = float2{ 0.5f * (za.x - zb.x), 0.5f * (za.y + zb.y) }; // (za - conj zb) / 2
+        const float2 wd = passes::cmul(d, w);
+        float2 v = MERGE ? float2{ e.x - wd.y, e.y + wd.x }  // E + i (conj(W) D)
+                         : float2{ e.x + wd.y, e.y - wd.x }; // E - i (W D)
+        if (r == 0 && t == 0)
+            v = MERGE ? float2{ 0.5f * (za.x + za.y), 0.5f * (za.x - za.y) } : float2{ za.x + za.y, za.x - za.y };
+        y[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        x[j] = y[j];
+}
+
 // X(h) for h = p >> SH (10 - SH bits): XOR of the rows of the bits set in h.  SH = 5: float2, SH = 4: double2
 template <int SH> struct rows;
 template <> struct rows<5> {
@@ -87,11 +122,13 @@ template <int SH> __device__ __forceinline__ uint32_t xterm_dev(uint32_t h)
 // fft_radix4(x); x[k] *= H[k]; fft_radix4<reverse_fft>(x)): the forward result X[t + 64 reversed(i)] in register i is the
 // input layout of the transform's own first pass, so after the per-bin multiply (h: natural order, 8 KiB, from L2) the
 // reverse transform runs on the same registers and LDS region with the conjugated thread twiddles; 1/N at the end.
-template <typename C, typename S, int RADIX, bool REV, int WAVES, bool CONV = false>
+// REAL (f32): 1 = real-input forward (split after the transform), 2 = real-input inverse (merge before it); h = W_2048^k
+template <typename C, typename S, int RADIX, bool REV, int WAVES, bool CONV = false, int REAL = 0>
 __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ data, const C *__restrict__ tw, uint64_t batch, S scale,
                                                                 const C *__restrict__ h = nullptr)
 {
     static_assert(!(CONV && REV), "the fused convolution belongs to forward plans");
+    static_assert(REAL == 0 || (sizeof(C) == 8 && !CONV && (REAL == 1) == !REV), "real-input packing: f32, split forward / merge inverse");
     constexpr int SH = sizeof(C) == 8 ? 5 : 4;
     __shared__ __attribute__((aligned(16))) C lds_all[WAVES][1024];
     const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -182,7 +219,11 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
 
     run_pass(std::integral_constant<int, 2>{}, rev_tag);
     };
+    if constexpr (REAL == 2)
+        real_pack_stage<16, true>(x, t, h, [](int r) { return r; });
     transform(std::integral_constant<bool, REV>{});
+    if constexpr (REAL == 1) // register i holds row row(i); both row maps are involutions
+        real_pack_stage<16, false>(x, t, h, [](int r) { return RADIX == 2 ? (int)(__brev((uint32_t)r) >> 28) : 4 * (r & 3) + (r >> 2); });
 
     if constexpr (CONV) {
         // x[i] = X[t + 64 row(i)]: multiply by h there and renumber so that register row(i) is element t + 64 row(i) -- the
@@ -284,11 +325,12 @@ template <bool REV, bool TW, int P, int S0> __device__ __forceinline__ void dif_
     }
 }
 
-template <int L, bool REV, bool CONV>
+template <int L, bool REV, bool CONV, int REAL = 0>
 __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ data, const float2 *__restrict__ tw, uint64_t batch, float scale,
                                                          const float2 *__restrict__ h)
 {
     static_assert(!(CONV && REV), "the fused convolution belongs to forward plans");
+    static_assert(REAL == 0 || (!CONV && (REAL == 1) == !REV), "real-input packing: split forward / merge inverse");
     constexpr int LP = L - 6, P = 1 << LP, N = 1 << L, NP = (L + LP - 1) / LP, REM = L - LP * (NP - 1);
     constexpr int TPW = P >= 16 ? 1 : 16 / P, R = P * TPW; // transforms per wave, registers per lane
     __shared__ __attribute__((aligned(16))) float2 lds_all[4][64 * R];
@@ -371,7 +413,17 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
             run_pass(std::integral_constant<int, 3>{});
         }
     };
+    if constexpr (REAL == 2) {
+#pragma unroll
+        for (int g = 0; g < TPW; g++)
+            real_pack_stage<P, true>(x + g * P, t, h, [](int r) { return r; });
+    }
     transform(std::integral_constant<bool, REV>{});
+    if constexpr (REAL == 1) {
+#pragma unroll
+        for (int g = 0; g < TPW; g++)
+            real_pack_stage<P, false>(x + g * P, t, h, [](int r) { return (int)(__brev((uint32_t)r) >> (32 - LP)); });
+    }
 
     if constexpr (CONV) {
         // register (g, k) holds X_g[t + 64 rev(k)]: multiply by h there, renumber to the first pass's input layout
@@ -400,13 +452,13 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
     }
 }
 
-template <int L, bool REV, bool CONV> int launch_w2(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool CONV, int REAL = 0> int launch_w2(const fft_reg_args &a, hipStream_t s)
 {
     constexpr int P = 1 << (L - 6), TPW = P >= 16 ? 1 : 16 / P;
     const uint64_t waves = (a.batch + TPW - 1) / TPW, blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL((sdsp_fft_wave_f32<L, REV, CONV>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
+    hipLaunchKernelGGL((sdsp_fft_wave_f32<L, REV, CONV, REAL>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
                        reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale, reinterpret_cast<const float2 *>(a.tw2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -415,6 +467,11 @@ template <int L, bool REV, bool CONV> int launch_w2(const fft_reg_args &a, hipSt
 }
 template <int L> int launch_w2_mode(const fft_reg_args &a, hipStream_t s)
 {
+    if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: tw2 = W_2N^k
+        if (!a.tw2 || (a.real_mode == 2) != (a.reverse != 0))
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "real-input packing: forward plans split, reverse plans merge");
+        return a.real_mode == 1 ? launch_w2<L, false, false, 1>(a, s) : launch_w2<L, true, false, 2>(a, s);
+    }
     if (a.real_mode == 3) {
         if (a.reverse || !a.tw2)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fused convolution needs a forward plan and h");
@@ -438,8 +495,32 @@ template <typename C, typename S, int RADIX, bool REV, bool CONV = false> int la
     return SDSP_HIP_OK;
 }
 
+template <typename C, typename S, int RADIX, int REAL> int launch_real_t(const fft_reg_args &a, S scale, hipStream_t s)
+{
+    constexpr int WAVES = 4;
+    const uint64_t blocks = (a.batch + WAVES - 1) / WAVES;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL((sdsp_fft1024_wave<C, S, RADIX, REAL == 2, WAVES, false, REAL>), dim3((uint32_t)blocks), dim3(64 * WAVES), 0, s,
+                       reinterpret_cast<C *>(a.data), reinterpret_cast<const C *>(a.tw), a.batch, scale,
+                       reinterpret_cast<const C *>(a.tw2));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_wave launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
 template <typename C, typename S> int launch_c(const fft_reg_args &a, S scale, hipStream_t s)
 {
+    if constexpr (sizeof(C) == 8) {
+        if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: tw2 = W_2N^k
+            if (!a.tw2 || (a.real_mode == 2) != (a.reverse != 0))
+                return fail(SDSP_HIP_ERR_INVALID_ARG, "real-input packing: forward plans split, reverse plans merge");
+            if (a.real_mode == 1)
+                return a.radix == 2 ? launch_real_t<C, S, 2, 1>(a, scale, s) : launch_real_t<C, S, 4, 1>(a, scale, s);
+            return a.radix == 2 ? launch_real_t<C, S, 2, 2>(a, scale, s) : launch_real_t<C, S, 4, 2>(a, scale, s);
+        }
+    }
     if (a.real_mode == 3) { // fused convolution: forward plan, tw2 = h
         if (a.reverse || !a.tw2)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fused convolution needs a forward plan and h");

@@ -180,6 +180,15 @@ class RfftPlan:
 
     __del__ = close
 
+    def set_variant(self, v: int):  # 0: the size's default kernel; 1 / 2: the register-pass family (A/B, cross-checks)
+        L.check(self._lib.sdsp_hip_fft_plan_set_variant(self._h, v))
+
+    @property
+    def info(self) -> L.PlanInfo:
+        i = L.PlanInfo()
+        L.check(self._lib.sdsp_hip_fft_plan_get_info(self._h, C.byref(i)))
+        return i
+
     def exec(self, x):
         """x: contiguous float32 device tensor (..., n_real), transformed in place; returns the complex
         view (forward) or x itself (reverse: pass the float32 view of the packed spectrum)."""

@@ -448,6 +448,7 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
 
 
 @pytest.mark.parametrize("n_real,radix,batch,precision", [(32, 2, 5, "f32"), (32, 4, 130, "f32"), (128, 4, 33, "f32"), (1024, 2, 7, "f32"),
+                                                           (512, 2, 1027, "f32"), (512, 2, 2, "f32"), (1024, 2, 130, "f32"), (2048, 2, 1030, "f32"), (4096, 2, 9, "f32"),
                                                            (2048, 4, 5, "f32"), (8192, 2, 3, "f32"), (8192, 4, 2, "f32"), (32768, 2, 2, "f32"),
                                                            (32, 2, 70, "f64"), (128, 4, 33, "f64"), (2048, 4, 5, "f64"), (16384, 2, 2, "f64")])
 def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precision):
@@ -481,6 +482,20 @@ def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precis
     again = inv.exec(torch.view_as_real(spec).reshape(batch, n_real))
     torch.cuda.synchronize()
     assert rel_max_err(again.cpu().numpy(), x) < 2 * TOL
+    # f32, n_real / 2 = 256 .. 2048: variant 0 is a one-wave kernel whose split / merge trades partners by ds_bpermute
+    # (csrc/fft_wave.hip: real_pack_stage); variant 1 the register-pass family's in-LDS split: the same numbers to rounding
+    wave = not f64 and radix == 2 and half in (256, 512, 1024)  # where the wave kernels measured faster (capi.hip)
+    assert fwd.info.kernel.decode() == ("sdsp_fft1024_wave" if wave and half == 1024 else "sdsp_fft_wave_f32" if wave else
+                                        "sdsp_fft_reg_f64_kernel" if f64 else "sdsp_fft_reg_kernel")
+    if wave:
+        fwd.set_variant(1)
+        inv.set_variant(1)
+        assert fwd.info.kernel.decode() == "sdsp_fft_reg_kernel"
+        spec1 = fwd.exec(torch.from_numpy(x).cuda())
+        back1 = inv.exec(torch.view_as_real(torch.from_numpy(want.astype(cdt)).cuda()).reshape(batch, n_real).contiguous())
+        torch.cuda.synchronize()
+        assert rel_max_err(spec1.cpu().numpy(), got) < 1e-6
+        assert rel_max_err(back1.cpu().numpy(), back.cpu().numpy()) < 1e-6
     with pytest.raises(sd.SdspHipError):
         sd.RfftPlan(4096, 4)  # n_real/2 = 2048 is not a power of 4
 
