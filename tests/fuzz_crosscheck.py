@@ -21,8 +21,11 @@ def rel(got, ref):
     return float(np.abs(np.asarray(got) - ref).max() / max(np.abs(ref).max(), 1e-300))
 
 
+default_piece = sd.get_launch_piece_bytes()
 for case in range(cases):
     kind = rng.choice(["fft", "fft", "iir", "fir", "conv", "rfft"])
+    # launch pieces (sdsp_hip_set_launch_piece_bytes): small pieces so that the batches of these cases are split too
+    sd.set_launch_piece_bytes(int(rng.choice([default_piece, default_piece, 0, 1 << 20, 3 << 19, 5 << 20])))
     try:
         if kind in ("fft", "conv", "rfft"):
             log2n = int(rng.integers(1, 22)) if kind == "fft" else int(rng.integers(4, 14))  # up to 2^21: nested three-pass plans
@@ -48,17 +51,22 @@ for case in range(cases):
             elif kind == "conv":
                 h = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
                 plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=batch)
+                cvar = int(rng.choice([0, 0, 1, 2]))  # fused kernel of the size / three launches / the register-pass fusion
+                plan.set_variant(cvar)
                 d = torch.from_numpy(x).cuda()
                 plan.convolve(d, torch.from_numpy(h).cuda())
                 torch.cuda.synchronize()
                 ref = np.fft.ifft(np.fft.fft(x.astype(np.complex128), axis=-1) * h.astype(np.complex128), axis=-1)
                 err, tol = rel(d.cpu().numpy(), ref), 2e-6
-                desc = f"conv n={n} r{radix} batch={batch}"
+                desc = f"conv n={n} r{radix} batch={batch} var={cvar}"
             else:
                 n_real = 2 * n
                 xr = rng.standard_normal((batch, n_real)).astype(np.float32)
                 fwd = sd.RfftPlan(n_real, radix, sd.forward_fft, max_batch=batch)
                 inv = sd.RfftPlan(n_real, radix, sd.reverse_fft, max_batch=batch)
+                rvar = int(rng.choice([0, 0, 1, 2]))  # the size's default kernel / the register-pass family's two cache policies
+                fwd.set_variant(rvar)
+                inv.set_variant(int(rng.choice([0, rvar])))
                 d = torch.from_numpy(xr).cuda()
                 fwd.exec(d)
                 torch.cuda.synchronize()
@@ -71,7 +79,7 @@ for case in range(cases):
                 torch.cuda.synchronize()
                 e2 = rel(d.cpu().numpy(), xr.astype(np.float64))
                 err, tol = max(e0, e1, e2 / 4), 1e-6
-                desc = f"rfft n_real={n_real} r{radix} batch={batch}"
+                desc = f"rfft n_real={n_real} r{radix} batch={batch} var={rvar}"
         elif kind == "iir":
             m = int(rng.choice([2, 4, 6, 8]))
             mode = int(rng.integers(0, 3))  # 0 f32, 1 f64, 2 float samples + double recurrence (SDSP_HIP_F32_F64STATE)
