@@ -147,11 +147,23 @@ int upload_thread_twiddles_reg(const std::vector<double> &w, uint32_t n, int rad
     return upload_twiddles(tab, precision, dev); // rounds to the plan precision exactly like the row itself
 }
 
-// Thread-twiddle table of fft_wave.hip's N = 256 / 512 / 2048 kernels: [global stage g][lane t] = W^((t mod s_i) << g) for
+// Thread-twiddle table of fft_wave.hip's N = 256 / 512 / 2048 kernels.  Radix 2: [global stage g][lane t] = W^((t mod s_i) << g) for
 // the stages of pass i < last (P = n / 64 points per lane, log2 P stages per pass, s_i = n >> (log2 P (i + 1))); the last
 // pass has no thread twiddles.
-int upload_thread_twiddles_wave(const std::vector<double> &w, uint32_t n, void **dev)
+int upload_thread_twiddles_wave(const std::vector<double> &w, uint32_t n, int radix, void **dev)
 {
+    if (radix == 4) { // N = 256: [pass i < 3][q = 1 .. 3][lane] = W^(q (t mod s_i) 4^i), s_i = 64 >> 2 i
+        std::vector<double> tab((size_t)3 * 3 * 64 * 2, 0.0);
+        for (uint32_t i = 0; i < 3; i++)
+            for (uint32_t q = 1; q < 4; q++)
+                for (uint32_t t = 0; t < 64; t++) {
+                    const size_t idx = (size_t)q * (t % (64u >> (2 * i))) << (2 * i);
+                    const size_t o = ((size_t)(i * 3 + q - 1) * 64 + t) * 2;
+                    tab[o] = w[2 * idx];
+                    tab[o + 1] = w[2 * idx + 1];
+                }
+        return upload_twiddles(tab, SDSP_HIP_F32, dev);
+    }
     const uint32_t L = sdsp_hip_log2(n), LP = L - 6, NP = (L + LP - 1) / LP;
     std::vector<double> tab((size_t)(NP - 1) * LP * 64 * 2, 0.0);
     for (uint32_t i = 0; i + 1 < NP; i++) {
@@ -716,7 +728,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
             rc = upload_thread_twiddles_big(w, n, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
-            rc = upload_thread_twiddles_wave(w, n, &p->twt_wave);
+            rc = upload_thread_twiddles_wave(w, n, radix, &p->twt_wave);
         if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
             rc = upload_thread_twiddles_mix(w, n, &p->twt_mix, &p->tw_lead);
         pick_tile(precision, n, std::max<uint32_t>(1, 1024 / n), &p->cols, &p->pitch);

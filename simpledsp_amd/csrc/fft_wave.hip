@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
 template <int L> struct rows2;
 template <> struct rows2<8> {
     static constexpr int SH = 4;
-    static constexpr uint32_t r[6] = { 4, 9, 16, 2, 0, 0 };
+    static constexpr uint32_t r[6] = { 4, 9, 17, 2, 0, 0 }; // conflict-free for the radix-2 and the radix-4 last-pass blocks
 };
 template <> struct rows2<9> {
     static constexpr int SH = 5;
@@ -325,12 +325,16 @@ template <bool REV, bool TW, int P, int S0> __device__ __forceinline__ void dif_
     }
 }
 
-template <int L, bool REV, bool CONV, int REAL = 0>
+// RADIX 4 (N = 256 = 4^4 only, P = 4): every pass is ONE radix-4 DIF stage (fft.h:311-349) on the lane's four points --
+// output q owes W_N^(q v 4^i), three thread twiddles per pass from a [pass][q][lane] table -- and the last pass takes the
+// block w = digit_reverse4(t), so that register k holds X[t + 64 k] (fft.h:351-355 folded into the assignment).
+template <int L, bool REV, bool CONV, int REAL = 0, int RADIX = 2>
 __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ data, const float2 *__restrict__ tw, uint64_t batch, float scale,
                                                          const float2 *__restrict__ h)
 {
     static_assert(!(CONV && REV), "the fused convolution belongs to forward plans");
     static_assert(REAL == 0 || (!CONV && (REAL == 1) == !REV), "real-input packing: split forward / merge inverse");
+    static_assert(RADIX == 2 || (RADIX == 4 && L == 8), "radix-4 stages: N = 256");
     constexpr int LP = L - 6, P = 1 << LP, N = 1 << L, NP = (L + LP - 1) / LP, REM = L - LP * (NP - 1);
     constexpr int TPW = P >= 16 ? 1 : 16 / P, R = P * TPW; // transforms per wave, registers per lane
     __shared__ __attribute__((aligned(16))) float2 lds_all[4][64 * R];
@@ -350,24 +354,38 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
             x[j] = gload(blk + 64 * j);
     }
 
-    const uint32_t w = __brev(t) >> 26;
+    // the last pass's block, and the row (register k -> X[t + 64 row(k)]) that follows from it
+    const uint32_t w = RADIX == 2 ? (__brev(t) >> 26) : (((t & 3u) << 4) | (t & 12u) | (t >> 4));
+    auto row_of = [](int k) { return RADIX == 2 ? (int)(__brev((uint32_t)k) >> (32 - LP)) : k; };
     auto transform = [&](auto rev_tag) {
         constexpr bool RV = decltype(rev_tag)::value;
         auto run_pass = [&](auto pass_tag) {
             constexpr int I = decltype(pass_tag)::value;
             constexpr bool last = I == NP - 1;
-            float2 wt[LP];
+            constexpr int NW = RADIX == 4 ? 3 : LP; // thread twiddles per pass
+            float2 wt[NW];
             if constexpr (!last) {
 #pragma unroll
-                for (int s = 0; s < LP; s++) {
-                    wt[s] = tw[(I * LP + s) * 64 + t];
+                for (int s = 0; s < NW; s++) {
+                    wt[s] = tw[(I * NW + s) * 64 + t];
                     if constexpr (RV != REV)
                         wt[s].y = -wt[s].y;
                 }
             }
 #pragma unroll
-            for (int g = 0; g < TPW; g++)
-                dif_p<RV, !last, P, (last ? LP - REM : 0)>(x + g * P, wt);
+            for (int g = 0; g < TPW; g++) {
+                if constexpr (RADIX == 4) {
+                    float2 *y = x + g * P;
+                    passes::bfly4<RV>(y[0], y[1], y[2], y[3]);
+                    if constexpr (!last) {
+                        y[1] = passes::cmul(y[1], wt[0]);
+                        y[2] = passes::cmul(y[2], wt[1]);
+                        y[3] = passes::cmul(y[3], wt[2]);
+                    }
+                } else {
+                    dif_p<RV, !last, P, (last ? LP - REM : 0)>(x + g * P, wt);
+                }
+            }
         };
         // slot address of register (g, k) in pass I's layout = g N + (A_I(t) ^ B_I(k))
         auto a_of = [&](auto pass_tag) -> uint32_t {
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
     if constexpr (REAL == 1) {
 #pragma unroll
         for (int g = 0; g < TPW; g++)
-            real_pack_stage<P, false>(x + g * P, t, h, [](int r) { return (int)(__brev((uint32_t)r) >> (32 - LP)); });
+            real_pack_stage<P, false>(x + g * P, t, h, row_of); // row_of is an involution: the register that holds row r
     }
 
     if constexpr (CONV) {
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
         float2 z[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            const int k = j % P, g = j / P, row = (int)(__brev((uint32_t)k) >> (32 - LP));
+            const int k = j % P, g = j / P, row = row_of(k);
             z[g * P + row] = passes::cmul(x[j], h[t + 64 * row]);
         }
 #pragma unroll
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
 
 #pragma unroll
     for (int j = 0; j < R; j++) {
-        const int k = j % P, g = j / P, row = (int)(__brev((uint32_t)k) >> (32 - LP));
+        const int k = j % P, g = j / P, row = row_of(k);
         float2 v = x[j];
         if constexpr (REV || CONV) { // reverse_fft::ScaleValues, fft.h:128-132
             v.x *= scale;
@@ -452,32 +470,32 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
     }
 }
 
-template <int L, bool REV, bool CONV, int REAL = 0> int launch_w2(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool CONV, int REAL = 0, int RADIX = 2> int launch_w2(const fft_reg_args &a, hipStream_t s)
 {
     constexpr int P = 1 << (L - 6), TPW = P >= 16 ? 1 : 16 / P;
     const uint64_t waves = (a.batch + TPW - 1) / TPW, blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL((sdsp_fft_wave_f32<L, REV, CONV, REAL>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
+    hipLaunchKernelGGL((sdsp_fft_wave_f32<L, REV, CONV, REAL, RADIX>), dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<float2 *>(a.data),
                        reinterpret_cast<const float2 *>(a.tw), a.batch, a.scale, reinterpret_cast<const float2 *>(a.tw2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_wave launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
-template <int L> int launch_w2_mode(const fft_reg_args &a, hipStream_t s)
+template <int L, int RADIX = 2> int launch_w2_mode(const fft_reg_args &a, hipStream_t s)
 {
     if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: tw2 = W_2N^k
         if (!a.tw2 || (a.real_mode == 2) != (a.reverse != 0))
             return fail(SDSP_HIP_ERR_INVALID_ARG, "real-input packing: forward plans split, reverse plans merge");
-        return a.real_mode == 1 ? launch_w2<L, false, false, 1>(a, s) : launch_w2<L, true, false, 2>(a, s);
+        return a.real_mode == 1 ? launch_w2<L, false, false, 1, RADIX>(a, s) : launch_w2<L, true, false, 2, RADIX>(a, s);
     }
     if (a.real_mode == 3) {
         if (a.reverse || !a.tw2)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fused convolution needs a forward plan and h");
-        return launch_w2<L, false, true>(a, s);
+        return launch_w2<L, false, true, 0, RADIX>(a, s);
     }
-    return a.reverse ? launch_w2<L, true, false>(a, s) : launch_w2<L, false, false>(a, s);
+    return a.reverse ? launch_w2<L, true, false, 0, RADIX>(a, s) : launch_w2<L, false, false, 0, RADIX>(a, s);
 }
 
 template <typename C, typename S, int RADIX, bool REV, bool CONV = false> int launch_t(const fft_reg_args &a, S scale, hipStream_t s)
@@ -537,10 +555,11 @@ bool fft_wave_supports(uint32_t n, int radix)
     return n == 1024 && (radix == 2 || radix == 4);
 }
 
-// N = 256 / 512 / 2048, radix-2 stages, f32: a.tw = the plan's [stage][lane] table (capi.hip: upload_thread_twiddles_wave)
+// N = 256 / 512 / 2048 radix-2 stages, N = 256 radix-4 stages, f32: a.tw = the plan's thread-twiddle table (capi.hip:
+// upload_thread_twiddles_wave)
 bool fft_wave2_supports(uint32_t n, int radix)
 {
-    return radix == 2 && (n == 256 || n == 512 || n == 2048);
+    return (radix == 2 && (n == 256 || n == 512 || n == 2048)) || (radix == 4 && n == 256);
 }
 
 int launch_fft_wave2_f32(const fft_reg_args &a, void *stream)
@@ -548,6 +567,8 @@ int launch_fft_wave2_f32(const fft_reg_args &a, void *stream)
     if (a.batch == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a.radix == 4 && a.n == 256)
+        return launch_w2_mode<8, 4>(a, s);
     if (a.radix == 2) {
         switch (a.n) {
         case 256: return launch_w2_mode<8>(a, s);

@@ -118,7 +118,7 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
 
 
 @pytest.mark.parametrize("n,radix,batch", [(16, 2, 1), (16, 4, 300), (32, 2, 129), (64, 4, 1000), (128, 2, 33), (256, 4, 17),
-                                           (512, 2, 9), (512, 2, 1031), (256, 2, 4098), (256, 2, 3), (2048, 2, 130), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
+                                           (512, 2, 9), (512, 2, 1031), (256, 2, 4098), (256, 2, 3), (256, 4, 4099), (256, 4, 2), (2048, 2, 130), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
                                            (8192, 2, 3), (16384, 2, 2), (16384, 4, 3)])
 def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
     # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
@@ -130,7 +130,7 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
         big = n >= 8192  # radix 2: registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
         mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
-        wave2 = radix == 2 and n in (256, 2048)  # csrc/fft_wave.hip: 1024 points (or one transform of 2048) per wave
+        wave2 = (radix == 2 and n in (256, 2048)) or (radix == 4 and n == 256)  # csrc/fft_wave.hip: 1024 points (or one transform of 2048) per wave
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
                                              "sdsp_fft_big_kernel" if big else
                                              "sdsp_fft1024_wave" if n == 1024 else  # csrc/fft_wave.hip: one transform per wave
@@ -415,7 +415,7 @@ def test_fft1m_schedules_agree(sd, torch_cuda, oracle):
 @pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
                                                      (256, 4, "f32", 33), (1024, 2, "f64", 4), (1 << 15, 2, "f32", 2),
                                                      (16, 2, "f32", 300), (64, 4, "f32", 70), (1024, 2, "f32", 9), (1024, 4, "f32", 1030),
-                                                     (256, 2, "f32", 1027), (512, 2, "f32", 77), (2048, 2, "f32", 35),
+                                                     (256, 2, "f32", 1027), (256, 4, "f32", 1026), (512, 2, "f32", 77), (2048, 2, "f32", 35),
                                                      (2048, 2, "f32", 3), (16384, 4, "f32", 2), (8192, 2, "f32", 2),
                                                      (64, 4, "f64", 70), (4096, 4, "f64", 3), (8192, 2, "f64", 2), (16384, 2, "f64", 2)])
 def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
@@ -433,7 +433,7 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
     tol = 2e-6 if prec == sd.F32 else 8 * n * EPS64  # two transforms and a product
     outs = []
     fused = n <= (16384 if prec == sd.F32 else 8192)
-    two_fused = prec == sd.F32 and (n == 1024 or (radix == 2 and n in (256, 512, 2048)))  # one-wave kernel + the register-pass MODE 3 (variant 2)
+    two_fused = prec == sd.F32 and (n in (256, 1024) or (radix == 2 and n in (512, 2048)))  # one-wave kernel + the register-pass MODE 3 (variant 2)
     for variant in ((0, 1, 2) if two_fused else (0, 1) if fused else (0,)):
         plan.set_variant(variant)  # f32 n <= 16384, f64 n <= 8192: 0 = fused single kernel, 1 = three launches
         d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
@@ -448,7 +448,7 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
 
 
 @pytest.mark.parametrize("n_real,radix,batch,precision", [(32, 2, 5, "f32"), (32, 4, 130, "f32"), (128, 4, 33, "f32"), (1024, 2, 7, "f32"),
-                                                           (512, 2, 1027, "f32"), (512, 2, 2, "f32"), (1024, 2, 130, "f32"), (2048, 2, 1030, "f32"), (4096, 2, 9, "f32"),
+                                                           (512, 2, 1027, "f32"), (512, 2, 2, "f32"), (512, 4, 1029, "f32"), (1024, 2, 130, "f32"), (2048, 2, 1030, "f32"), (4096, 2, 9, "f32"),
                                                            (2048, 4, 5, "f32"), (8192, 2, 3, "f32"), (8192, 4, 2, "f32"), (32768, 2, 2, "f32"),
                                                            (32, 2, 70, "f64"), (128, 4, 33, "f64"), (2048, 4, 5, "f64"), (16384, 2, 2, "f64")])
 def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precision):
@@ -484,7 +484,7 @@ def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precis
     assert rel_max_err(again.cpu().numpy(), x) < 2 * TOL
     # f32, n_real / 2 = 256 .. 2048: variant 0 is a one-wave kernel whose split / merge trades partners by ds_bpermute
     # (csrc/fft_wave.hip: real_pack_stage); variant 1 the register-pass family's in-LDS split: the same numbers to rounding
-    wave = not f64 and radix == 2 and half in (256, 512, 1024)  # where the wave kernels measured faster (capi.hip)
+    wave = not f64 and (half == 256 or (radix == 2 and half in (512, 1024)))  # where the wave kernels measured faster (capi.hip)
     assert fwd.info.kernel.decode() == ("sdsp_fft1024_wave" if wave and half == 1024 else "sdsp_fft_wave_f32" if wave else
                                         "sdsp_fft_reg_f64_kernel" if f64 else "sdsp_fft_reg_kernel")
     if wave:

@@ -40,15 +40,16 @@ def layouts_1024(radix):
     return B + C, A + B
 
 
-def layouts_p(L):
-    """N = 256 / 512 / 2048 (sdsp_fft_wave_f32): pass i < last: b (s P) + v + s k; last: P w + k; reads / writes."""
+def layouts_p(L, radix=2):
+    """N = 256 / 512 / 2048 (sdsp_fft_wave_f32): pass i < last: b (s P) + v + s k; last: P w + k, w = bit_reverse6(t) or (radix 4,
+    N = 256) digit_reverse4(t); reads / writes."""
     LP = L - 6
     P, N, NP = 1 << LP, 1 << L, -(-L // LP)
     lay = []
     for i in range(NP - 1):
         sg = N >> (LP * (i + 1))
         lay.append([[(t // sg) * (sg * P) + (t % sg) + sg * k for t in range(64)] for k in range(P)])
-    lay.append([[P * brev(t, 6) + k for t in range(64)] for k in range(P)])
+    lay.append([[P * (brev(t, 6) if radix == 2 else drev3(t)) + k for t in range(64)] for k in range(P)])
     return [p for l in lay[1:] for p in l], [p for l in lay[:-1] for p in l]
 
 
@@ -68,7 +69,7 @@ def free(rows, sh, reads, writes, g_r, m_r, g_w, m_w):
 CASES = {  # name: (rows, SH, N, [(reads, writes), ...], read groups / modulus, write groups / modulus)
     "rows<5>  N = 1024 f32, both radices": ([16, 29, 6, 23, 18], 5, 1024, [layouts_1024(2), layouts_1024(4)], G_R64, 32, G_W64, 16),
     "rows<4>  N = 1024 f64, both radices": ([5, 3, 15, 1, 6, 9], 4, 1024, [layouts_1024(2), layouts_1024(4)], G_R128, 16, G_W128, 8),
-    "rows2<8>  N = 256": ([4, 9, 16, 2], 4, 256, [layouts_p(8)], G_R64, 32, G_W64, 16),
+    "rows2<8>  N = 256, both radices": ([4, 9, 17, 2], 4, 256, [layouts_p(8), layouts_p(8, 4)], G_R64, 32, G_W64, 16),
     "rows2<9>  N = 512": ([10, 28, 15, 18], 5, 512, [layouts_p(9)], G_R64, 32, G_W64, 16),
     "rows2<11> N = 2048": ([25, 23, 13, 5, 7, 30], 5, 2048, [layouts_p(11)], G_R64, 32, G_W64, 16),
 }
