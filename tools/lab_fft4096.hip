@@ -78,6 +78,9 @@ __global__ void checksum_kernel(const uint2 *p, size_t n, unsigned long long *ou
 //   pieces     the same buffer in launches of 65536 transforms (launch length held, address range grows)
 //   first      launches of 65536 transforms on the first piece only (both held)
 //   whole xcd  one launch, every XCD walking its own contiguous eighth
+//   2 streams  launches of 32768 transforms (1 GiB), alternating between two streams (piece i of every pass on stream i % 2,
+//              so a piece's forward and reverse launches stay ordered): the tail of one launch overlaps the head of the next
+//   1 GiB      the same pieces on one stream (what the library does)
 static int size_study(uint64_t batch, int rounds)
 {
     const size_t n = batch * 4096;
@@ -105,8 +108,25 @@ static int size_study(uint64_t batch, int rounds)
     const float scale = 1.0f / 4096.0f;
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, data, n, 9u);
     const uint64_t piece = 65536;
+    hipStream_t st[2];
+    CK(hipStreamCreate(&st[0]));
+    CK(hipStreamCreate(&st[1]));
     auto run = [&](int mode, bool rev) {
         const float2 *w = rev ? twr : twf;
+        if (mode == 4 || mode == 5) {
+            const uint64_t pc = 32768;
+            int i = 0;
+            for (uint64_t off = 0; off < batch; off += pc, i++) {
+                float2 *d = data + off * 4096;
+                const uint64_t b = std::min(pc, batch - off);
+                hipStream_t q = mode == 4 ? st[i & 1] : (hipStream_t)0;
+                if (rev)
+                    hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, 1, 2, 0, 0, 3>), dim3((uint32_t)b), dim3(256), 0, q, d, w, b, scale);
+                else
+                    hipLaunchKernelGGL((sdsp_fft4096_r4_f32<false, 1, 2, 0, 0, 3>), dim3((uint32_t)b), dim3(256), 0, q, d, w, b, scale);
+            }
+            return;
+        }
         if (mode == 0) {
             if (rev)
                 hipLaunchKernelGGL((sdsp_fft4096_r4_f32<true, 1, 2, 0, 0, 3>), dim3((uint32_t)batch), dim3(256), 0, 0, data, w, batch, scale);
@@ -131,23 +151,25 @@ static int size_study(uint64_t batch, int rounds)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const char *names[4] = { "whole", "pieces", "first", "whole xcd" };
+    const char *names[6] = { "whole", "pieces", "first", "whole xcd", "2 streams", "1 GiB" };
     for (int i = 0; i < 30; i++) {
         run(2, false);
         run(2, true);
     }
     std::printf("batch %llu = %.1f GiB\n", (unsigned long long)batch, (double)n * 8 / (1 << 30));
     for (int round = 0; round < rounds; round++)
-        for (int mode = 0; mode < 4; mode++) {
+        for (int mode = 0; mode < 6; mode++) {
             for (int i = 0; i < 3; i++) {
                 run(mode, false);
                 run(mode, true);
             }
+            CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
             for (int i = 0; i < 6; i++) {
                 run(mode, false);
                 run(mode, true);
             }
+            CK(hipDeviceSynchronize()); // the two-stream mode runs beside the null stream's events
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms = 0;
