@@ -32,6 +32,28 @@ __device__ __forceinline__ float2 *at(float2 *base, uint32_t byte_off)
 {
     return reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off);
 }
+// Rows of one transform through a buffer resource: `buffer_load/store_dwordx2 v, voffset, s[rsrc], soffset offen` takes the
+// row's byte offset in an SGPR (any size) next to ONE per-thread VGPR offset.  With rows 4-8 KiB apart -- beyond the 13-bit
+// immediate of global_load -- the compiler builds a 64-bit VGPR address per row from plain pointers however they are written
+// (it reassociates to (base + thread) + row); at N = 32768 it then spilled 18 of those pairs and reloaded each in front of its
+// store behind an s_waitcnt vmcnt(0), which serialised the store phase.
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rows(const float2 *base, uint32_t bytes)
+{
+    // word 3 = 0x00020000: DATA_FORMAT 32 (raw dword access), no swizzle, no index stride -- the gfx9 / CDNA raw-buffer setting
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, (int)bytes, 0x00020000);
+}
+template <bool NT> __device__ __forceinline__ float2 row_load(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rows, thread_off, row_off, NT ? 2 : 0); // aux bit 1 = nt
+    const unsigned int lo = v.x, hi = v.y; // (__builtin_bit_cast applied to v.y directly reads element 0: seen with ROCm 7.2's clang)
+    return float2{ __uint_as_float(lo), __uint_as_float(hi) };
+}
+template <bool NT> __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off, float2 a)
+{
+    const v2u_t v = { __float_as_uint(a.x), __float_as_uint(a.y) };
+    __builtin_amdgcn_raw_buffer_store_b64(v, rows, thread_off, row_off, NT ? 2 : 0);
+}
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)

@@ -47,50 +47,89 @@ template <int L> __device__ __forceinline__ uint32_t sw(uint32_t p)
     return p ^ ((((p >> (5 + R)) & ((1u << (5 - R)) - 1)) << R) | ((p >> 10) & ((1u << R) - 1)));
 }
 
+// sw's XOR term for any position whose 32-block index (position >> (5 + R)) is k: k's five bits rotated by R
+template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
+{
+    return ((k & ((1u << (5 - R)) - 1)) << R) | ((k >> (5 - R)) & ((1u << R) - 1));
+}
+
 // G transforms per workgroup (consecutive in memory), each on its own N/32 threads and LDS plane.  G = 1 is what
 // ships: at N = 4096 larger
 // workgroups measured slower -- 69.9 % (G = 1), 66.9 % (G = 2), 63.2 % (G = 4) -- the barriers span more waves.
-template <int L, bool REV, bool NT, int G = 1>
+template <int L, bool REV, bool NT, int G = 1, int LAB = 0, bool PERSIST = false>
 // four waves per SIMD for every size: at N = 8192 that costs 20-36 B/lane of scratch, but three workgroups
 // per CU without scratch measured 61 % against 67 %
 __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                                           float scale, uint64_t batch)
+                                                                           float scale, uint64_t batch, uint32_t stag_first,
+                                                                           uint32_t stag_n, uint32_t stag_ticks)
 {
+    static_assert(G == 1, "one transform per workgroup (larger workgroups measured slower; the row buffer needs a uniform base)");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
+    if (stag_n && blockIdx.x < stag_first) { // LAB: staggered start of the first round of workgroups
+        const uint64_t t0 = wall_clock64();
+        const uint64_t want = (uint64_t)((blockIdx.x >> 3) % stag_n) * stag_ticks;
+        while (wall_clock64() - t0 < want)
+            __builtin_amdgcn_s_sleep(16);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[];
-    const uint32_t g = threadIdx.x / T;
-    float *plane = reinterpret_cast<float *>(sdsp_fft_big_smem) + g * N; // N floats per transform
+    const uint32_t g = G == 1 ? 0u : threadIdx.x / T;
+    const uint32_t plane_off = g * N * 4u; // N floats per transform
+    auto lds_f32 = [&](uint32_t byte) -> float & { return *reinterpret_cast<float *>(sdsp_fft_big_smem + byte); };
 
-    const uint32_t t = threadIdx.x % T;
-    const uint64_t xform = static_cast<uint64_t>(blockIdx.x) * G + g;
-    const bool live = xform < batch; // ragged last workgroup: idle threads still meet the barriers
-    float2 *base = data + (live ? xform : 0) * N;
+    const uint32_t t = G == 1 ? threadIdx.x : threadIdx.x % T;
     const uint32_t toff = t * 8u;
+    // PERSIST (G == 1): the workgroup walks transforms blockIdx.x, + gridDim.x, ...; the loads of the next transform are issued
+    // right behind the stores of this one, so the two memory phases of a CU that holds ONE workgroup overlap
+    for (uint64_t xform = static_cast<uint64_t>(blockIdx.x) * G + g; PERSIST ? xform < batch : true; xform += gridDim.x) {
+    const bool live = xform < batch; // ragged last workgroup: idle threads still meet the barriers
+    const __amdgpu_buffer_rsrc_t rows = make_rows(data + (live ? xform : 0) * N, N * sizeof(float2)); // fft32.h: why a buffer
 
     float2 x[32];
-    if (G == 1 || live) {
+    if constexpr (LAB == 1) {
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            x[k] = NT ? nt_load(at(base + T * k, toff)) : *at(base + T * k, toff);
+            x[k] = float2{ (float)(t + k) * scale, (float)(t ^ k) * scale };
+    } else if (G == 1 || live) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            x[k] = row_load<NT>(rows, toff, T * k * sizeof(float2));
     }
-
+    if constexpr (LAB != 2) {
     fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
 
+    // LDS byte addresses of the three access patterns.  sw<L>() only ever XORs a 5-bit term into the low five bits of a
+    // position, and in every pattern that term is a compile-time constant or a per-thread constant, so an access costs
+    // at most ONE v_xor (the generic expression cost 4-6 integer operations per access: 1100-1550 of the kernel's
+    // 3000-3350 vector instructions were address arithmetic).  With rot(k) = sw's term for a position in 32-block k:
+    //   pattern A  position k*M + t          ->  4*k*M + (4t ^ 4*rot(k))                 rot(k) is a literal
+    //   pattern B  position pb + (j << R)    ->  baseB[j mod 2^(5-R)] + 128*(j >> (5-R))  no arithmetic per access
+    //   pattern C  position 32*w + i         ->  (128*w + 4*xc) ^ 4*i                     xc per thread
+    // (checked against sw<L> for every thread and register of the three sizes: tools/model_fft_big_lds.py)
     const uint32_t blk = t >> R, v = t & ((1u << R) - 1);
-    const uint32_t pb = blk * M + v; // pass-B position of register j: pb + (j << R)
+    constexpr int JL = 1 << (5 - R); // pattern B: the low 5 - R bits of j meet the thread's XOR term
+    const uint32_t xb = rot5<R>(blk);
+    uint32_t base_b[JL];
+#pragma unroll
+    for (int jl = 0; jl < JL; jl++)
+        base_b[jl] = plane_off + 4u * (blk * M + (v ^ (xb & ((1u << R) - 1))) + (((uint32_t)jl ^ (xb >> R)) << R));
+    const uint32_t w = __brev(t) >> (32 - (L - 5));
+    const uint32_t base_c = plane_off + ((128u * w) | (4u * ((((w >> R) & ((1u << (5 - R)) - 1)) << R) | ((w >> 5) & ((1u << R) - 1)))));
+    const uint32_t base_a = plane_off + 4u * t;
     // ---- exchange A -> B, one plane at a time
+    if constexpr (PERSIST)
+        __syncthreads(); // the previous transform's last plane has been read by every wave
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        uint32_t ta = t, tb = pb;
-        asm volatile("" : "+v"(ta), "+v"(tb)); // keep the 64 swizzled addresses out of long-lived registers
+        uint32_t ta = base_a;
+        asm volatile("" : "+v"(ta)); // keep the 32 addresses of a plane out of long-lived registers
 #pragma unroll
         for (int k = 0; k < 32; k++)
-            plane[sw<L>(k * M + ta)] = half ? x[k].y : x[k].x;
+            lds_f32(4u * k * M + (ta ^ (4u * rot5<R>(k)))) = half ? x[k].y : x[k].x;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 32; j++) {
-            const float f = plane[sw<L>(tb + (j << R))];
+            const float f = lds_f32(base_b[j % JL] + 128u * (j / JL));
             if (half)
                 x[j].y = f;
             else
@@ -102,18 +141,17 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
     fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T);
 
     // ---- exchange B -> C
-    const uint32_t w = __brev(t) >> (32 - (L - 5));
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        uint32_t tb = pb, tc = 32u * w;
-        asm volatile("" : "+v"(tb), "+v"(tc));
+        uint32_t tc = base_c;
+        asm volatile("" : "+v"(tc));
 #pragma unroll
         for (int j = 0; j < 32; j++)
-            plane[sw<L>(tb + (j << R))] = half ? x[j].y : x[j].x;
+            lds_f32(base_b[j % JL] + 128u * (j / JL)) = half ? x[j].y : x[j].x;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
-            const float f = plane[sw<L>(tc + i)];
+            const float f = lds_f32(tc ^ (4u * i));
             if (half)
                 x[i].y = f;
             else
@@ -124,10 +162,25 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
     }
 
     fft32_dif<REV, false, 5 - R>(x, tw, 0);
+    } // LAB != 2
+    if constexpr (LAB == 1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            acc += x[i].x * x[i].y;
+        if (acc != 12345.678f) {
+            if constexpr (PERSIST)
+                continue;
+            else
+                return;
+        }
+    }
 
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
-    if (G > 1 && !live)
-        return;
+    if constexpr (G > 1) {
+        if (!live)
+            return;
+    }
 #pragma unroll
     for (int i = 0; i < 32; i++) {
         float2 o = x[i];
@@ -135,28 +188,62 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
             o.x *= scale;
             o.y *= scale;
         }
-        float2 *dst = at(base + T * (int)(__brev((uint32_t)i) >> 27), toff);
-        if constexpr (NT)
-            nt_store(dst, o);
-        else
-            *dst = o;
+        row_store<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(float2), o);
     }
+    if constexpr (!PERSIST)
+        break;
+    } // transforms of this workgroup
 }
 
-template <int L, bool REV, bool NT, int G = 1> int launch_l(const fft_reg_args &a, hipStream_t s)
+struct lab_knobs {
+    int lab = 0;
+    uint32_t first = 0, n = 0, ticks = 0;
+    int persist = -1, per_cu = 0;
+};
+inline lab_knobs read_lab()
+{
+    lab_knobs k;
+    if (const char *e = getenv("SDSP_LAB_BIG"))
+        sscanf(e, "%d,%u,%u,%u,%d,%d", &k.lab, &k.first, &k.n, &k.ticks, &k.persist, &k.per_cu);
+    return k;
+}
+
+int cu_count()
+{
+    static std::atomic<int> cached{ 0 };
+    int g = cached.load();
+    if (g)
+        return g;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return 256;
+    g = prop.multiProcessorCount;
+    cached.store(g);
+    return g;
+}
+
+template <int L, bool REV, bool NT, int G = 1, int LAB = 0, bool PERSIST = false> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = (sizeof(float) << L) * G;
-    auto kern = sdsp_fft_big_kernel<L, REV, NT, G>;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT, G, LAB, PERSIST>;
+    const lab_knobs kn = read_lab();
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
             return rc;
     }
-    const uint64_t blocks = (a.batch + G - 1) / G;
+    uint64_t blocks = (a.batch + G - 1) / G;
+    if constexpr (PERSIST) {
+        constexpr int kPerCu = L == 15 ? 1 : L == 14 ? 2 : 4;
+        const uint64_t resident = (uint64_t)cu_count() * (kn.per_cu > 0 ? kn.per_cu : kPerCu);
+        if (blocks > resident)
+            blocks = resident;
+    }
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(G * (1u << L) / 32), lds, s, reinterpret_cast<float2 *>(a.data),
-                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch);
+                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch, kn.first, kn.n, kn.ticks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big launch: ") + hipGetErrorString(e));
@@ -165,6 +252,15 @@ template <int L, bool REV, bool NT, int G = 1> int launch_l(const fft_reg_args &
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
+    if constexpr (L >= 14) {
+        const lab_knobs kn = read_lab();
+        if (kn.lab == 1)
+            return kn.persist == 1 ? launch_l<L, true, true, 1, 1, true>(a, s) : launch_l<L, true, true, 1, 1>(a, s);
+        if (kn.lab == 2)
+            return kn.persist == 1 ? launch_l<L, true, true, 1, 2, true>(a, s) : launch_l<L, true, true, 1, 2>(a, s);
+        if (kn.persist == 1 && a.nontemporal)
+            return a.reverse ? launch_l<L, true, true, 1, 0, true>(a, s) : launch_l<L, false, true, 1, 0, true>(a, s);
+    }
     if (a.nontemporal)
         return a.reverse ? launch_l<L, true, true>(a, s) : launch_l<L, false, true>(a, s);
     return a.reverse ? launch_l<L, true, false>(a, s) : launch_l<L, false, false>(a, s);
