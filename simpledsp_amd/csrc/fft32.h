@@ -54,6 +54,13 @@ template <bool NT> __device__ __forceinline__ void row_store(__amdgpu_buffer_rsr
     const v2u_t v = { __float_as_uint(a.x), __float_as_uint(a.y) };
     __builtin_amdgcn_raw_buffer_store_b64(v, rows, thread_off, row_off, NT ? 2 : 0);
 }
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+typedef float v4f32_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void row_store16(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off, v4f32_t a)
+{
+    const v4u_t v = { __float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w) };
+    __builtin_amdgcn_raw_buffer_store_b128(v, rows, thread_off, row_off, NT ? 2 : 0);
+}
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return float2{ a.x + b.x, a.y + b.y }; }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{ a.x - b.x, a.y - b.y }; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)

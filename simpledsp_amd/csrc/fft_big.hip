@@ -3,9 +3,10 @@
 //
 // These sizes are too large for the register-pass family's "whole tile in LDS" scheme to keep more
 // than one workgroup on a CU (N = 16384 is 128 KiB of complex f32), so nothing overlapped the load and
-// store phases there (44-51 % of HBM peak; this kernel: 67 % at 8192, 60 % at 16384, 41 % at 32768 --
+// store phases there (44-51 % of HBM peak; this kernel: 73-76 % at 8192, 69 % at 16384, 56 % at 32768 --
 // where the previous path was the two-pass four-step).  In-place read+write traffic plateaus at 74-77 % of
-// 8 TB/s on this part whatever the shape (tools/delaybench.hip), so what is left here is on-chip work.  Here the transform lives in REGISTERS, 32 points per
+// 8 TB/s on this part whatever the shape (tools/delaybench.hip), and a CU that holds two workgroups of 128 KiB / one of
+// 256 KiB caps at ~70 % / ~65 % even with no arithmetic between the loads and the stores (tools/cucap.hip).  Here the transform lives in REGISTERS, 32 points per
 // thread (N/32 threads per transform, one transform per workgroup), and LDS is only the exchange medium
 // between register passes -- moved one plane (real, then imaginary) at a time, so a transform needs
 // 4*N bytes of LDS and TWO workgroups of N = 16384 (four of N = 8192) share a CU:
@@ -41,7 +42,7 @@ using namespace fft32;
 // on p >> (5+R), so 2^(5+R) consecutive positions stay consecutive (pattern A is untouched).
 // (A first version spread 64 lanes over 64 banks -- the wrong model for b32 accesses -- and left pattern C with
 // 2-way conflicts: 69.2 / 60.9 / 41.2 % where this one gives 70.3 / 61.5 / 43.1 % at N = 8192 / 16384 / 32768.)
-template <int L> __device__ __forceinline__ uint32_t sw(uint32_t p)
+template <int L> [[maybe_unused]] __device__ __forceinline__ uint32_t sw(uint32_t p) // the layout's definition; the kernel uses the forms below
 {
     constexpr int R = L - 10;
     return p ^ ((((p >> (5 + R)) & ((1u << (5 - R)) - 1)) << R) | ((p >> 10) & ((1u << R) - 1)));
@@ -53,49 +54,31 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
     return ((k & ((1u << (5 - R)) - 1)) << R) | ((k >> (5 - R)) & ((1u << R) - 1));
 }
 
-// G transforms per workgroup (consecutive in memory), each on its own N/32 threads and LDS plane.  G = 1 is what
-// ships: at N = 4096 larger
-// workgroups measured slower -- 69.9 % (G = 1), 66.9 % (G = 2), 63.2 % (G = 4) -- the barriers span more waves.
-template <int L, bool REV, bool NT, int G = 1, int LAB = 0, bool PERSIST = false>
-// four waves per SIMD for every size: at N = 8192 that costs 20-36 B/lane of scratch, but three workgroups
-// per CU without scratch measured 61 % against 67 %
-__global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                                           float scale, uint64_t batch, uint32_t stag_first,
-                                                                           uint32_t stag_n, uint32_t stag_ticks)
+// One transform per workgroup (two / four consecutive transforms on a larger workgroup measured slower at N = 4096:
+// 69.9 % (1), 66.9 % (2), 63.2 % (4) -- the barriers span more waves).
+// Four waves per SIMD for every size (<= 128 VGPRs: 124 / 124 / 127 at N = 8192 / 16384 / 32768, no scratch).
+template <int L, bool REV, bool NT>
+__global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                                       float scale, uint64_t batch)
 {
-    static_assert(G == 1, "one transform per workgroup (larger workgroups measured slower; the row buffer needs a uniform base)");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
-    if (stag_n && blockIdx.x < stag_first) { // LAB: staggered start of the first round of workgroups
-        const uint64_t t0 = wall_clock64();
-        const uint64_t want = (uint64_t)((blockIdx.x >> 3) % stag_n) * stag_ticks;
-        while (wall_clock64() - t0 < want)
-            __builtin_amdgcn_s_sleep(16);
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[];
-    const uint32_t g = G == 1 ? 0u : threadIdx.x / T;
-    const uint32_t plane_off = g * N * 4u; // N floats per transform
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[]; // N floats: one plane of the transform
     auto lds_f32 = [&](uint32_t byte) -> float & { return *reinterpret_cast<float *>(sdsp_fft_big_smem + byte); };
 
-    const uint32_t t = G == 1 ? threadIdx.x : threadIdx.x % T;
+    const uint32_t t = threadIdx.x;
     const uint32_t toff = t * 8u;
-    // PERSIST (G == 1): the workgroup walks transforms blockIdx.x, + gridDim.x, ...; the loads of the next transform are issued
-    // right behind the stores of this one, so the two memory phases of a CU that holds ONE workgroup overlap
-    for (uint64_t xform = static_cast<uint64_t>(blockIdx.x) * G + g; PERSIST ? xform < batch : true; xform += gridDim.x) {
-    const bool live = xform < batch; // ragged last workgroup: idle threads still meet the barriers
-    const __amdgpu_buffer_rsrc_t rows = make_rows(data + (live ? xform : 0) * N, N * sizeof(float2)); // fft32.h: why a buffer
+    const uint64_t xform = blockIdx.x;
+    if (xform >= batch)
+        return;
+    // the transform's rows (T elements = 2 / 4 / 8 KiB apart) through a buffer resource: fft32.h, make_rows
+    const __amdgpu_buffer_rsrc_t rows = make_rows(data + xform * N, N * sizeof(float2));
 
     float2 x[32];
-    if constexpr (LAB == 1) {
 #pragma unroll
-        for (int k = 0; k < 32; k++)
-            x[k] = float2{ (float)(t + k) * scale, (float)(t ^ k) * scale };
-    } else if (G == 1 || live) {
-#pragma unroll
-        for (int k = 0; k < 32; k++)
-            x[k] = row_load<NT>(rows, toff, T * k * sizeof(float2));
-    }
-    if constexpr (LAB != 2) {
+    for (int k = 0; k < 32; k++)
+        x[k] = row_load<NT>(rows, toff, T * k * sizeof(float2));
+
     fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
 
     // LDS byte addresses of the three access patterns.  sw<L>() only ever XORs a 5-bit term into the low five bits of a
@@ -112,13 +95,11 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
     uint32_t base_b[JL];
 #pragma unroll
     for (int jl = 0; jl < JL; jl++)
-        base_b[jl] = plane_off + 4u * (blk * M + (v ^ (xb & ((1u << R) - 1))) + (((uint32_t)jl ^ (xb >> R)) << R));
+        base_b[jl] = 4u * (blk * M + (v ^ (xb & ((1u << R) - 1))) + (((uint32_t)jl ^ (xb >> R)) << R));
     const uint32_t w = __brev(t) >> (32 - (L - 5));
-    const uint32_t base_c = plane_off + ((128u * w) | (4u * ((((w >> R) & ((1u << (5 - R)) - 1)) << R) | ((w >> 5) & ((1u << R) - 1)))));
-    const uint32_t base_a = plane_off + 4u * t;
+    const uint32_t base_c = (128u * w) | (4u * ((((w >> R) & ((1u << (5 - R)) - 1)) << R) | ((w >> 5) & ((1u << R) - 1))));
+    const uint32_t base_a = 4u * t;
     // ---- exchange A -> B, one plane at a time
-    if constexpr (PERSIST)
-        __syncthreads(); // the previous transform's last plane has been read by every wave
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint32_t ta = base_a;
@@ -162,25 +143,8 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
     }
 
     fft32_dif<REV, false, 5 - R>(x, tw, 0);
-    } // LAB != 2
-    if constexpr (LAB == 1) {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; i++)
-            acc += x[i].x * x[i].y;
-        if (acc != 12345.678f) {
-            if constexpr (PERSIST)
-                continue;
-            else
-                return;
-        }
-    }
 
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
-    if constexpr (G > 1) {
-        if (!live)
-            return;
-    }
 #pragma unroll
     for (int i = 0; i < 32; i++) {
         float2 o = x[i];
@@ -190,60 +154,21 @@ __global__ __launch_bounds__(G * (1 << L) / 32, 4) void sdsp_fft_big_kernel(floa
         }
         row_store<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(float2), o);
     }
-    if constexpr (!PERSIST)
-        break;
-    } // transforms of this workgroup
 }
 
-struct lab_knobs {
-    int lab = 0;
-    uint32_t first = 0, n = 0, ticks = 0;
-    int persist = -1, per_cu = 0;
-};
-inline lab_knobs read_lab()
+template <int L, bool REV, bool NT> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
-    lab_knobs k;
-    if (const char *e = getenv("SDSP_LAB_BIG"))
-        sscanf(e, "%d,%u,%u,%u,%d,%d", &k.lab, &k.first, &k.n, &k.ticks, &k.persist, &k.per_cu);
-    return k;
-}
-
-int cu_count()
-{
-    static std::atomic<int> cached{ 0 };
-    int g = cached.load();
-    if (g)
-        return g;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        return 256;
-    g = prop.multiProcessorCount;
-    cached.store(g);
-    return g;
-}
-
-template <int L, bool REV, bool NT, int G = 1, int LAB = 0, bool PERSIST = false> int launch_l(const fft_reg_args &a, hipStream_t s)
-{
-    constexpr size_t lds = (sizeof(float) << L) * G;
-    auto kern = sdsp_fft_big_kernel<L, REV, NT, G, LAB, PERSIST>;
-    const lab_knobs kn = read_lab();
+    constexpr size_t lds = sizeof(float) << L;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
             return rc;
     }
-    uint64_t blocks = (a.batch + G - 1) / G;
-    if constexpr (PERSIST) {
-        constexpr int kPerCu = L == 15 ? 1 : L == 14 ? 2 : 4;
-        const uint64_t resident = (uint64_t)cu_count() * (kn.per_cu > 0 ? kn.per_cu : kPerCu);
-        if (blocks > resident)
-            blocks = resident;
-    }
-    if (blocks > 0x7fffffffull)
+    if (a.batch > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(G * (1u << L) / 32), lds, s, reinterpret_cast<float2 *>(a.data),
-                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch, kn.first, kn.n, kn.ticks);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)a.batch), dim3((1u << L) / 32), lds, s, reinterpret_cast<float2 *>(a.data),
+                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big launch: ") + hipGetErrorString(e));
@@ -252,15 +177,6 @@ template <int L, bool REV, bool NT, int G = 1, int LAB = 0, bool PERSIST = false
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
-    if constexpr (L >= 14) {
-        const lab_knobs kn = read_lab();
-        if (kn.lab == 1)
-            return kn.persist == 1 ? launch_l<L, true, true, 1, 1, true>(a, s) : launch_l<L, true, true, 1, 1>(a, s);
-        if (kn.lab == 2)
-            return kn.persist == 1 ? launch_l<L, true, true, 1, 2, true>(a, s) : launch_l<L, true, true, 1, 2>(a, s);
-        if (kn.persist == 1 && a.nontemporal)
-            return a.reverse ? launch_l<L, true, true, 1, 0, true>(a, s) : launch_l<L, false, true, 1, 0, true>(a, s);
-    }
     if (a.nontemporal)
         return a.reverse ? launch_l<L, true, true>(a, s) : launch_l<L, false, true>(a, s);
     return a.reverse ? launch_l<L, true, false>(a, s) : launch_l<L, false, false>(a, s);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Lab: sdsp_fft_big_kernel (N = 16384 / 32768) under the SDSP_LAB_BIG knobs -- compute-only, memory-only and a
+"""Lab (needs tools/lab_patches/fft_big_lab.patch applied to csrc/fft_big.hip): sdsp_fft_big_kernel under the SDSP_LAB_BIG knobs -- compute-only, memory-only and a
 staggered start of the first round of workgroups.  SDSP_LAB_BIG = "lab,first,groups,ticks" (ticks of 10 ns)."""
 import os
 import sys
