@@ -27,6 +27,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "fft32.h"
+
 #include "fft_passes.h"
 
 namespace sdsp_hip
@@ -251,6 +253,9 @@ __global__ __launch_bounds__(256, WAVES) void sdsp_fft4096_r4_f32(float2 *__rest
     if (f >= batch)
         return;
     float2 x[16];
+    // plain pointers: the compiler builds 64-bit VGPR addresses for most rows (2 KiB apart), but at 84 VGPRs that costs this
+    // kernel nothing, and the buffer-resource form that pays off in fft_big.hip and in the convolution below measured
+    // 0.5 points SLOWER here (A/B in one run, 2 GiB batches: 75.1-75.2 % against 75.7-76.1 %)
     const float2 *src = data + f * 4096 + t;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -339,29 +344,31 @@ __global__ __launch_bounds__(256, 2) void sdsp_fft4096_conv_f32(float2 *__restri
         wB2[r - 1] = tw[1536 + (r + 2) * 16 + rr];
     }
     const lds_map mp = make_lds_map<false>(lds, t);
+    const __amdgpu_buffer_rsrc_t hrows = fft32::make_rows(h, 4096 * sizeof(float2));
 
     for (uint64_t f = blockIdx.x; f < batch; f += gridDim.x) {
         float2 x[16], z[16];
-        const float2 *src = data + f * 4096 + t;
+        // data and H rows through buffer resources (fft32.h: make_rows): with plain pointers the 32 + 16 row addresses were
+        // 64-bit VGPR pairs and the kernel needed 126 VGPRs (four workgroups per CU); this form needs 92 (five) -- 57 -> 66 %
+        const __amdgpu_buffer_rsrc_t rows = fft32::make_rows(data + f * 4096, 4096 * sizeof(float2));
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            x[k] = gload(src + 256 * k);
+            x[k] = fft32::row_load<true>(rows, t * 8u, 256u * 8u * k);
         fft4096_in_regs<false>(x, lds, mp, wA1, wA2, wB1, wB2);
         // x[k] = X[t + 256 j], j = 4 (k & 3) + (k >> 2): multiply by H[t + 256 j] and renumber so that
         // z[j] is element t + 256 j of the spectrum -- the input layout of the transform's first pass
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = 4 * (k & 3) + (k >> 2);
-            z[j] = cmul(x[k], h[t + 256 * j]);
+            z[j] = cmul(x[k], fft32::row_load<false>(hrows, t * 8u, 256u * 8u * j));
         }
         fft4096_in_regs<REVERSE_HALF>(z, lds, mp, wA1, wA2, wB1, wB2);
-        float2 *dst = data + f * 4096 + t;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             float2 v = z[k];
             v.x *= 1.0f / 4096.0f; // reverse_fft::ScaleValues, fft.h:128-132
             v.y *= 1.0f / 4096.0f;
-            gstore(dst + 256 * (4 * (k & 3) + (k >> 2)), v);
+            fft32::row_store<true>(rows, t * 8u, 256u * 8u * (4 * (k & 3) + (k >> 2)), v);
         }
     }
 }
