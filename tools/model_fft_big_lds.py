@@ -16,7 +16,7 @@ def brev(x, bits):
     return int(format(x, "0%db" % bits)[::-1], 2)
 
 
-for L in (13, 14, 15):
+for L in (11, 12, 13, 14, 15):
     R = L - 10
     N = 1 << L
     T = M = N // 32
