@@ -198,6 +198,39 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
     return SDSP_HIP_OK;
 }
 
+// Thread-twiddle table of fft_big.hip's radix-4 form (N = 16384 = 4^7, fft32_r4.h): [slot < 14][thread t < 512].  Slots 0-2:
+// W_N^(q t); 3-5: W_4096^(q t); 6, 7: stage 2's pair for the thread's block parity -- (1, W_1024^(2v)) for an even block,
+// (W_1024^v, W_1024^(3v)) for an odd one; 8-10: W_256^(q v); 11-13: W_64^(q v); q = 1, 2, 3, v = t mod 16, block = t / 16.
+// `w` is the row W_N^j, direction-folded.  tools/model_fft_big_r4.py is the index arithmetic's model.
+int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void **dev)
+{
+    const uint32_t T = n / 32;
+    std::vector<float> tab((size_t)14 * T * 2);
+    auto put = [&](uint32_t slot, uint32_t t, uint64_t idx) {
+        idx %= n;
+        tab[((size_t)slot * T + t) * 2] = (float)w[2 * idx];
+        tab[((size_t)slot * T + t) * 2 + 1] = (float)w[2 * idx + 1];
+    };
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t v = t & 15, odd = (t >> 4) & 1;
+        for (uint32_t q = 1; q <= 3; q++) {
+            put(q - 1, t, (uint64_t)q * t);           // W_N^(q t)
+            put(2 + q, t, (uint64_t)4 * q * t);       // W_4096^(q t) = W_N^(4 q t)
+            put(7 + q, t, (uint64_t)(n / 256) * q * v); // W_256^(q v)
+            put(10 + q, t, (uint64_t)(n / 64) * q * v); // W_64^(q v)
+        }
+        put(6, t, odd ? (uint64_t)(n / 1024) * v : 0);                       // j < 16: q = 1 (odd block) / none
+        put(7, t, (uint64_t)(n / 1024) * (odd ? 3 : 2) * v);                 // j >= 16: q = 3 (odd) / 2 (even)
+    }
+    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SDSP_HIP_OK;
+}
+
+// N = 16384 radix-4 plans: fft_big.hip's radix-4 form is variant 0 and the fft_mix.hip kernel variant 1; the other sizes
+// fft_mix.hip serves keep it as variant 0 and fft_big.hip's radix-2 stages as variant 1
+inline bool big_is_default(uint32_t n, int radix) { return n == 16384 && radix == 4; }
+
 constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 // Tables of fft_mix.hip (N = R x 4096, R = 2 / 4): the N = 4096 radix-4 thread-twiddle table built from W_4096^j = W_N^(R j),
@@ -329,7 +362,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
 
     // N = 8192 / 16384 f32, either stage type: one leading radix-2 / radix-4 stage + the tuned N = 4096 radix-4 machinery
     const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
-    if (mix_size && variant == 0) {
+    const int mix_variant = big_is_default(p->n, p->radix) ? 1 : 0;
+    if (mix_size && variant == mix_variant) {
         fft_mix_args a;
         a.data = data;
         a.tw = p->twt_mix;
@@ -343,7 +377,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
 
     // N = 32768 (variant 0) and N = 8192 / 16384 (variant 1), f32: radix-2 stages, registers-resident single-pass kernel
     // (fft_big.hip)
-    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == (mix_size ? 1 : 0) &&
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == (mix_size ? 1 - mix_variant : 0) &&
         !p->real_mode && fft_big_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
@@ -669,8 +703,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
     if (radix_auto) {
         if (!sdsp_hip_is_power_of_2(n))
             return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT size must be a power of 2!");
-        // the stage type of the fastest kernel of the size: radix 4 where n is a power of 4 -- except n = 16384, where the
-        // radix-2-stage kernel (fft_big.hip) and the radix-4 one (fft_mix.hip) measure the same 58-61 % of HBM peak
+        // the stage type of the fastest kernel of the size: radix 4 where n is a power of 4 -- except n = 16384, where
+        // fft_big.hip's radix-2 stages measure 69-70 % of HBM peak and its seven radix-4 stages 67-69 %
         radix = (sdsp_hip_is_power_of_4(n) && n != 16384) ? 4 : 2;
     }
     // the reference's static_asserts (fft.h:261, :304) as run-time checks
@@ -726,7 +760,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                     (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))))
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
-            rc = upload_thread_twiddles_big(w, n, &p->twt_big);
+            rc = big_is_default(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
             rc = upload_thread_twiddles_wave(w, n, radix, &p->twt_wave);
         if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
@@ -1035,8 +1069,9 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->precision = p->precision;
     info->device = p->device;
     const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
+    const int mix_variant = big_is_default(p->n, p->radix) ? 1 : 0;
     const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 &&
-                     p->variant == (mix_size ? 1 : 0) && !p->real_mode && fft_big_supports(p->n, p->radix);
+                     p->variant == (mix_size ? 1 - mix_variant : 0) && !p->real_mode && fft_big_supports(p->n, p->radix);
     const bool two_pass = p->path == PATH_FOUR_STEP && p->precision == SDSP_HIP_F32 && fft_2pass_supports(p->n);
     const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == (two_pass ? 1 : 0);
     info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
@@ -1063,7 +1098,7 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = "sdsp_fft_wave_f32";
     if (big)
         name = "sdsp_fft_big_kernel";
-    if (mix_size && p->variant == 0)
+    if (mix_size && p->variant == mix_variant)
         name = "sdsp_fft_mix_f32";
     if (mid)
         name = "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16";

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fft32.h"
+#include "fft32_r4.h"
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
@@ -57,7 +58,10 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // One transform per workgroup (two / four consecutive transforms on a larger workgroup measured slower at N = 4096:
 // 69.9 % (1), 66.9 % (2), 63.2 % (4) -- the barriers span more waves).
 // Four waves per SIMD for every size (<= 128 VGPRs: 124 / 124 / 127 at N = 8192 / 16384 / 32768, no scratch).
-template <int L, bool REV, bool NT>
+// R4 (N = 16384 = 4^7 only): the fourteen layers run as seven radix-4 DIF stages (fft32_r4.h) -- two stages, then half of the
+// third in pass A; its other half and two stages in pass B; two stages in pass C -- with their own thread-twiddle table
+// (capi.hip: upload_thread_twiddles_big_r4); loads, exchanges and the store are the same.
+template <int L, bool REV, bool NT, bool R4 = false>
 __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                        float scale, uint64_t batch)
 {
@@ -79,7 +83,29 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     for (int k = 0; k < 32; k++)
         x[k] = row_load<NT>(rows, toff, T * k * sizeof(float2));
 
-    fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
+    if constexpr (R4) {
+        static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
+        float2 thr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tw[q * T + t]; // W_N^((q + 1) t)
+        r4_stage<REV, 4, 7, 2, true>(x, thr); // stage 0: quarter = register bits 4, 3; constant W_32^(q (k & 7))
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tw[(3 + q) * T + t]; // W_4096^((q + 1) t)
+        r4_stage<REV, 2, 1, 8, true>(x, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
+        // stage 2, first layer: register bit 0 is index bit 9, index bit 8 is the thread's: the quarter (1, 1) = odd registers of
+        // the threads t >= 256
+        layer<1>(x);
+        const bool upper = t >= 256;
+#pragma unroll
+        for (int k = 1; k < 32; k += 2) {
+            const float2 r = rot_i<REV>(x[k]);
+            x[k] = float2{ upper ? r.x : x[k].x, upper ? r.y : x[k].y };
+        }
+    } else {
+        fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
+    }
 
     // LDS byte addresses of the three access patterns.  sw<L>() only ever XORs a 5-bit term into the low five bits of a
     // position, and in every pattern that term is a compile-time constant or a per-thread constant, so an access costs
@@ -119,7 +145,21 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
         __syncthreads();
     }
 
-    fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T);
+    if constexpr (R4) {
+        layer<16>(x); // stage 2, second layer: register bit 4 is index bit 8
+        r4_split_twiddles<REV>(x, (blk & 1u) != 0, tw[6 * T + t], tw[7 * T + t], std::make_integer_sequence<int, 32>{});
+        float2 thr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tw[(8 + q) * T + t]; // W_256^((q + 1) v)
+        r4_stage<REV, 3, 3, 4, true>(x, thr); // stage 3: register bits 3, 2; constant W_16^(q (j & 3))
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tw[(11 + q) * T + t]; // W_64^((q + 1) v)
+        r4_stage<REV, 1, 0, 0, true>(x, thr); // stage 4: register bits 1, 0; thread twiddles only
+    } else {
+        fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T);
+    }
 
     // ---- exchange B -> C
 #pragma unroll
@@ -142,7 +182,13 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
             __syncthreads();
     }
 
-    fft32_dif<REV, false, 5 - R>(x, tw, 0);
+    if constexpr (R4) {
+        const float2 none[3] = {};
+        r4_stage<REV, 3, 3, 4, false>(x, none); // stage 5: register bits 3, 2; constants W_16^(q (i & 3)) only
+        r4_layers<REV, 1>(x);                   // stage 6: no twiddles
+    } else {
+        fft32_dif<REV, false, 5 - R>(x, tw, 0);
+    }
 
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
 #pragma unroll
@@ -156,10 +202,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     }
 }
 
-template <int L, bool REV, bool NT> int launch_l(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool NT, bool R4 = false> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = sizeof(float) << L;
-    auto kern = sdsp_fft_big_kernel<L, REV, NT>;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
@@ -177,17 +223,18 @@ template <int L, bool REV, bool NT> int launch_l(const fft_reg_args &a, hipStrea
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
+    if constexpr (L == 14) {
+        if (a.radix == 4) // a.tw: the radix-4 table
+            return a.reverse ? launch_l<L, true, true, true>(a, s) : launch_l<L, false, true, true>(a, s);
+    }
     if (a.nontemporal)
         return a.reverse ? launch_l<L, true, true>(a, s) : launch_l<L, false, true>(a, s);
     return a.reverse ? launch_l<L, true, false>(a, s) : launch_l<L, false, false>(a, s);
 }
 } // namespace
 
-// Radix-4 plans of N = 16384 run here too: a radix-4 DIF stage (fft.h:311-349) is two fused radix-2 DIF
-// stages (the inner twiddle is -+i), so the 5 + 5 + 4 radix-2 stages of this kernel are the same dataflow as
-// the reference's seven radix-4 stages run unfused; the natural-order result is the same DFT to rounding
-// (tests hold it to the same 1e-6 against the oracle's radix-4 algorithm).  The register-pass family's
-// genuine two-stage radix-4 passes remain as variants 1 / 2 of such plans.
+// Radix-4 plans of N = 16384 run here too, as seven genuine radix-4 DIF stages (the R4 form of the kernel, fft32_r4.h)
+// on their own thread-twiddle table.
 bool fft_big_supports(uint32_t n, int radix)
 {
     if (radix == 4)

@@ -128,10 +128,11 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x.astype(np.complex128), radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        big = n >= 8192  # radix 2: registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there
-        mix = (n, radix) == (16384, 4)  # radix 4: leading radix-4 stage + the N = 4096 machinery (csrc/fft_mix.hip); fft_big = variant 1
+        big = n >= 8192  # registers-resident single-pass kernel (csrc/fft_big.hip) is variant 0 there: radix-2 stages, or the
+        # seven radix-4 stages of (16384, 4) -- whose variant 1 is csrc/fft_mix.hip (leading radix-4 stage + the N = 4096 machinery)
+        mix = (n, radix) == (16384, 4)
         wave2 = (radix == 2 and n in (256, 2048)) or (radix == 4 and n == 256)  # csrc/fft_wave.hip: 1024 points (or one transform of 2048) per wave
-        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else "sdsp_fft_mix_f32" if mix else
+        assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else
                                              "sdsp_fft_big_kernel" if big else
                                              "sdsp_fft1024_wave" if n == 1024 else  # csrc/fft_wave.hip: one transform per wave
                                              "sdsp_fft_wave_f32" if wave2 else "sdsp_fft_reg_kernel")
@@ -156,8 +157,9 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
 @pytest.mark.parametrize("n,radix,ref_radix", [(8192, 0, 2), (16384, 4, 4)])
 @pytest.mark.parametrize("batch", [1, 5, 300])
 def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch):
-    """csrc/fft_mix.hip: N = 2 * 4^6 through the radix-4 kernel with one radix-2 stage (plans of radix AUTO),
-    N = 4^7 with genuine radix-4 stages (sdsp::fft_radix4<T,16384>, fft.h:301-360).  Against the oracle's algorithm of the
+    """csrc/fft_mix.hip (SURVEY 8f-4): N = 2 * 4^6 through the radix-4 kernel with one radix-2 stage (plans of radix AUTO);
+    N = 4^7 with genuine radix-4 stages (sdsp::fft_radix4<T,16384>, fft.h:301-360) in csrc/fft_big.hip's radix-4 form
+    (default) and in csrc/fft_mix.hip (variant 1).  Against the oracle's algorithm of the
     stage type the plan reports, against the radix-2-stage kernel (variant 1) on every transform, both directions, and
     the round trip."""
     torch = torch_cuda
@@ -166,7 +168,9 @@ def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch)
     pick = sorted({0, batch - 1, batch // 2})
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        assert plan.info.kernel.decode() == "sdsp_fft_mix_f32" and plan.info.hbm_passes == 1 and plan.info.radix == ref_radix
+        # (16384, 4): the default is fft_big.hip's radix-4 form and fft_mix.hip variant 1; (8192, AUTO): the other way round
+        first, second = ("sdsp_fft_big_kernel", "sdsp_fft_mix_f32") if n == 16384 else ("sdsp_fft_mix_f32", "sdsp_fft_big_kernel")
+        assert plan.info.kernel.decode() == first and plan.info.hbm_passes == 1 and plan.info.radix == ref_radix
         d = torch.from_numpy(x).cuda()
         guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
         plan.exec(d)
@@ -176,7 +180,7 @@ def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch)
         want = oracle.fft(x[pick].astype(np.complex128), ref_radix, rev)
         assert rel_max_err(got[pick], want) < TOL32, rel_max_err(got[pick], want)
         plan.set_variant(1)
-        assert plan.info.kernel.decode() == "sdsp_fft_big_kernel"
+        assert plan.info.kernel.decode() == second
         d2 = torch.from_numpy(x).cuda()
         plan.exec(d2)
         torch.cuda.synchronize()
@@ -188,7 +192,7 @@ def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch)
     inv.exec(d)
     torch.cuda.synchronize()
     assert rel_max_err(d.cpu().numpy(), x) < TOL32
-    # an explicit radix 2 is honoured: radix-2 butterflies only; AUTO at 16384 picks that kernel too (it is the faster one)
+    # an explicit radix 2 is honoured: radix-2 butterflies only; AUTO at 16384 picks that form too (2 points faster than the radix-4 one)
     assert sd.FftPlan(n, 2, sd.forward_fft, sd.F32).info.kernel.decode() == "sdsp_fft_big_kernel"
     auto = sd.FftPlan(16384, 0, sd.forward_fft, sd.F32).info
     assert auto.kernel.decode() == "sdsp_fft_big_kernel" and auto.radix == 2
