@@ -1006,6 +1006,22 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
 {
     if (p->path == PATH_FFT4096 && p->variant == 0)
         return launch_fft4096_conv_f32(data, p->twt, h, batch, stream);
+    // N = 8192 / 16384 / 32768, radix-2 stages: both transforms and the multiply in the registers-resident kernel (fft_big.hip)
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode &&
+        p->radix == 2 && p->twt_big && fft_big_supports(p->n, p->radix)) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->twt_big;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = 0;
+        a.nontemporal = 1;
+        a.real_mode = 3;
+        a.tw2 = h;
+        return launch_fft_big_f32(a, stream);
+    }
     // variant 0: the fused kernel of the size; variant 2: the register-pass family's fused MODE 3 where a one-wave kernel
     // is the default (A/B and cross-check); any other variant: three launches
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && (p->variant == 0 || p->variant == 2) && !p->real_mode) {

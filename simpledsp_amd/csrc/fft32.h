@@ -111,15 +111,20 @@ __device__ constexpr float kS32[16] = { 0.0f,
 // S0 > 0 skips the first S0 stages: the 32 registers then hold 2^S0 independent groups of 32 >> S0 points.
 // TABLE: wsrc points at the thread's column of a [stage][thread] thread-twiddle table with row pitch u, so
 // stage s reads wsrc[s * u] (coalesced across lanes) instead of gathering wsrc[u << s] from the row W^j.
-template <bool REV, bool TW, int S0 = 0, bool TABLE = false>
+// CONJ: the table holds the other direction's values (the fused convolution runs its reverse transform on the forward
+// plan's table): conjugate what is fetched.
+template <bool REV, bool TW, int S0 = 0, bool TABLE = false, bool CONJ = false>
 __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, uint32_t u)
 {
 #pragma unroll
     for (int s = S0; s < 5; s++) {
         const int h = 16 >> s;
         float2 ws = float2{ 1.0f, 0.0f };
-        if constexpr (TW)
+        if constexpr (TW) {
             ws = TABLE ? wsrc[s * u] : wsrc[u << s];
+            if constexpr (CONJ)
+                ws.y = -ws.y;
+        }
 #pragma unroll
         for (int k = 0; k < 32; k++) {
             if ((k & h) != 0)

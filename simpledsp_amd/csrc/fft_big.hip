@@ -61,10 +61,17 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // R4 (N = 16384 = 4^7 only): the fourteen layers run as seven radix-4 DIF stages (fft32_r4.h) -- two stages, then half of the
 // third in pass A; its other half and two stages in pass B; two stages in pass C -- with their own thread-twiddle table
 // (capi.hip: upload_thread_twiddles_big_r4); loads, exchanges and the store are the same.
-template <int L, bool REV, bool NT, bool R4 = false>
+// CONV (forward radix-2 plans): the fused fast convolution data <- IFFT(FFT(data) .* h) of SURVEY 8(f)-1.  The forward
+// transform leaves register i holding X[t + T * bit_reverse5(i)]; multiplied by h there (rows of h through a buffer resource,
+// default cache policy: every workgroup reads the same N points) and RENAMED z[bit_reverse5(i)] = x[i], that is the input
+// layout of pass A, so the reverse transform (conjugated table values, +i rotations, 1/N at the store) runs on the same
+// registers and the same LDS plane: one HBM read and one write per element instead of three of each.
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false>
 __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                                       float scale, uint64_t batch)
+                                                                       float scale, uint64_t batch, const float2 *__restrict__ h)
 {
+    static_assert(!CONV || (!REV && !R4), "the fused convolution belongs to forward plans of radix-2 stages");
+    static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[]; // N floats: one plane of the transform
@@ -82,30 +89,6 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
 #pragma unroll
     for (int k = 0; k < 32; k++)
         x[k] = row_load<NT>(rows, toff, T * k * sizeof(float2));
-
-    if constexpr (R4) {
-        static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
-        float2 thr[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            thr[q] = tw[q * T + t]; // W_N^((q + 1) t)
-        r4_stage<REV, 4, 7, 2, true>(x, thr); // stage 0: quarter = register bits 4, 3; constant W_32^(q (k & 7))
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            thr[q] = tw[(3 + q) * T + t]; // W_4096^((q + 1) t)
-        r4_stage<REV, 2, 1, 8, true>(x, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
-        // stage 2, first layer: register bit 0 is index bit 9, index bit 8 is the thread's: the quarter (1, 1) = odd registers of
-        // the threads t >= 256
-        layer<1>(x);
-        const bool upper = t >= 256;
-#pragma unroll
-        for (int k = 1; k < 32; k += 2) {
-            const float2 r = rot_i<REV>(x[k]);
-            x[k] = float2{ upper ? r.x : x[k].x, upper ? r.y : x[k].y };
-        }
-    } else {
-        fft32_dif<REV, true, 0, true>(x, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
-    }
 
     // LDS byte addresses of the three access patterns.  sw<L>() only ever XORs a 5-bit term into the low five bits of a
     // position, and in every pattern that term is a compile-time constant or a per-thread constant, so an access costs
@@ -125,76 +108,126 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     const uint32_t w = __brev(t) >> (32 - (L - 5));
     const uint32_t base_c = (128u * w) | (4u * ((((w >> R) & ((1u << (5 - R)) - 1)) << R) | ((w >> 5) & ((1u << R) - 1))));
     const uint32_t base_a = 4u * t;
-    // ---- exchange A -> B, one plane at a time
+
+    // the transform on the registers: y[k] = element t + T k  ->  y[i] = result[t + T * bit_reverse5(i)].  RV: its direction;
+    // CJ: the table holds the other direction's thread twiddles; AGAIN: the LDS plane may still be read by the transform before
+    auto transform = [&](float2 (&y)[32], auto rev_tag, auto conj_tag, auto again_tag) {
+        constexpr bool RV = decltype(rev_tag)::value, CJ = decltype(conj_tag)::value, AGAIN = decltype(again_tag)::value;
+        if constexpr (R4) {
+            float2 thr[3];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        uint32_t ta = base_a;
-        asm volatile("" : "+v"(ta)); // keep the 32 addresses of a plane out of long-lived registers
+            for (int q = 0; q < 3; q++)
+                thr[q] = tw[q * T + t]; // W_N^((q + 1) t)
+            r4_stage<RV, 4, 7, 2, true>(y, thr); // stage 0: quarter = register bits 4, 3; constant W_32^(q (k & 7))
 #pragma unroll
-        for (int k = 0; k < 32; k++)
-            lds_f32(4u * k * M + (ta ^ (4u * rot5<R>(k)))) = half ? x[k].y : x[k].x;
-        __syncthreads();
+            for (int q = 0; q < 3; q++)
+                thr[q] = tw[(3 + q) * T + t]; // W_4096^((q + 1) t)
+            r4_stage<RV, 2, 1, 8, true>(y, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
+            // stage 2, first layer: register bit 0 is index bit 9, index bit 8 is the thread's: the quarter (1, 1) = odd
+            // registers of the threads t >= 256
+            layer<1>(y);
+            const bool upper = t >= 256;
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const float f = lds_f32(base_b[j % JL] + 128u * (j / JL));
-            if (half)
-                x[j].y = f;
-            else
-                x[j].x = f;
+            for (int k = 1; k < 32; k += 2) {
+                const float2 r = rot_i<RV>(y[k]);
+                y[k] = float2{ upper ? r.x : y[k].x, upper ? r.y : y[k].y };
+            }
+        } else {
+            fft32_dif<RV, true, 0, true, CJ>(y, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
         }
-        __syncthreads();
-    }
 
-    if constexpr (R4) {
-        layer<16>(x); // stage 2, second layer: register bit 4 is index bit 8
-        r4_split_twiddles<REV>(x, (blk & 1u) != 0, tw[6 * T + t], tw[7 * T + t], std::make_integer_sequence<int, 32>{});
-        float2 thr[3];
+        // ---- exchange A -> B, one plane at a time
+        if constexpr (AGAIN)
+            __syncthreads(); // every wave has read the previous transform's last plane
 #pragma unroll
-        for (int q = 0; q < 3; q++)
-            thr[q] = tw[(8 + q) * T + t]; // W_256^((q + 1) v)
-        r4_stage<REV, 3, 3, 4, true>(x, thr); // stage 3: register bits 3, 2; constant W_16^(q (j & 3))
+        for (int half = 0; half < 2; half++) {
+            uint32_t ta = base_a;
+            asm volatile("" : "+v"(ta)); // keep the 32 addresses of a plane out of long-lived registers
 #pragma unroll
-        for (int q = 0; q < 3; q++)
-            thr[q] = tw[(11 + q) * T + t]; // W_64^((q + 1) v)
-        r4_stage<REV, 1, 0, 0, true>(x, thr); // stage 4: register bits 1, 0; thread twiddles only
-    } else {
-        fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T);
-    }
+            for (int k = 0; k < 32; k++)
+                lds_f32(4u * k * M + (ta ^ (4u * rot5<R>(k)))) = half ? y[k].y : y[k].x;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const float f = lds_f32(base_b[j % JL] + 128u * (j / JL));
+                if (half)
+                    y[j].y = f;
+                else
+                    y[j].x = f;
+            }
+            __syncthreads();
+        }
 
-    // ---- exchange B -> C
+        if constexpr (R4) {
+            layer<16>(y); // stage 2, second layer: register bit 4 is index bit 8
+            r4_split_twiddles<RV>(y, (blk & 1u) != 0, tw[6 * T + t], tw[7 * T + t], std::make_integer_sequence<int, 32>{});
+            float2 thr[3];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        uint32_t tc = base_c;
-        asm volatile("" : "+v"(tc));
+            for (int q = 0; q < 3; q++)
+                thr[q] = tw[(8 + q) * T + t]; // W_256^((q + 1) v)
+            r4_stage<RV, 3, 3, 4, true>(y, thr); // stage 3: register bits 3, 2; constant W_16^(q (j & 3))
 #pragma unroll
-        for (int j = 0; j < 32; j++)
-            lds_f32(base_b[j % JL] + 128u * (j / JL)) = half ? x[j].y : x[j].x;
-        __syncthreads();
+            for (int q = 0; q < 3; q++)
+                thr[q] = tw[(11 + q) * T + t]; // W_64^((q + 1) v)
+            r4_stage<RV, 1, 0, 0, true>(y, thr); // stage 4: register bits 1, 0; thread twiddles only
+        } else {
+            fft32_dif<RV, true, 0, true, CJ>(y, tw + 5 * T + t, T);
+        }
+
+        // ---- exchange B -> C
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t tc = base_c;
+            asm volatile("" : "+v"(tc));
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                lds_f32(base_b[j % JL] + 128u * (j / JL)) = half ? y[j].y : y[j].x;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const float f = lds_f32(tc ^ (4u * i));
+                if (half)
+                    y[i].y = f;
+                else
+                    y[i].x = f;
+            }
+            if (half == 0)
+                __syncthreads();
+        }
+
+        if constexpr (R4) {
+            const float2 none[3] = {};
+            r4_stage<RV, 3, 3, 4, false>(y, none); // stage 5: register bits 3, 2; constants W_16^(q (i & 3)) only
+            r4_layers<RV, 1>(y);                   // stage 6: no twiddles
+        } else {
+            fft32_dif<RV, false, 5 - R>(y, tw, 0);
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+
+    transform(x, std::integral_constant<bool, REV>{}, no{}, no{});
+
+    if constexpr (CONV) {
+        // x[i] = X[t + T * bit_reverse5(i)]: times h there, renamed into pass A's input order (no data moves: a renaming)
+        const __amdgpu_buffer_rsrc_t hrows = make_rows(h, N * sizeof(float2));
+        float2 z[32];
 #pragma unroll
         for (int i = 0; i < 32; i++) {
-            const float f = lds_f32(tc ^ (4u * i));
-            if (half)
-                x[i].y = f;
-            else
-                x[i].x = f;
+            const int k = (int)(__brev((uint32_t)i) >> 27);
+            z[k] = cmul(x[i], row_load<false>(hrows, toff, T * k * sizeof(float2)));
         }
-        if (half == 0)
-            __syncthreads();
-    }
-
-    if constexpr (R4) {
-        const float2 none[3] = {};
-        r4_stage<REV, 3, 3, 4, false>(x, none); // stage 5: register bits 3, 2; constants W_16^(q (i & 3)) only
-        r4_layers<REV, 1>(x);                   // stage 6: no twiddles
-    } else {
-        fft32_dif<REV, false, 5 - R>(x, tw, 0);
+        transform(z, yes{}, yes{}, yes{});
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            x[i] = z[i];
     }
 
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
 #pragma unroll
     for (int i = 0; i < 32; i++) {
         float2 o = x[i];
-        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+        if constexpr (REV || CONV) { // reverse_fft::ScaleValues, fft.h:128-132
             o.x *= scale;
             o.y *= scale;
         }
@@ -202,10 +235,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     }
 }
 
-template <int L, bool REV, bool NT, bool R4 = false> int launch_l(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = sizeof(float) << L;
-    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4>;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4, CONV>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
@@ -214,7 +247,7 @@ template <int L, bool REV, bool NT, bool R4 = false> int launch_l(const fft_reg_
     if (a.batch > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL(kern, dim3((uint32_t)a.batch), dim3((1u << L) / 32), lds, s, reinterpret_cast<float2 *>(a.data),
-                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch);
+                       reinterpret_cast<const float2 *>(a.tw), a.scale, a.batch, reinterpret_cast<const float2 *>(a.tw2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big launch: ") + hipGetErrorString(e));
@@ -223,6 +256,11 @@ template <int L, bool REV, bool NT, bool R4 = false> int launch_l(const fft_reg_
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
+    if (a.real_mode == 3) { // fused convolution (forward radix-2 plans): a.tw2 = h
+        if (a.reverse || a.radix != 2 || !a.tw2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big convolution: forward radix-2 plan and a filter spectrum needed");
+        return launch_l<L, false, true, false, true>(a, s);
+    }
     if constexpr (L == 14) {
         if (a.radix == 4) // a.tw: the radix-4 table
             return a.reverse ? launch_l<L, true, true, true>(a, s) : launch_l<L, false, true, true>(a, s);
