@@ -196,7 +196,7 @@ public:
     }
     // fast convolution: data <- IFFT(FFT(data) .* h) per transform, in place; needs a
     // FORWARD plan; device pointers; h = n complex values (frequency response, natural order).
-    // One fused kernel for float n = 16 .. 16384 and double n = 16 .. 8192; three launches beyond.
+    // One fused kernel for float n = 16 .. 16384 (radix 2: .. 32768) and double n = 16 .. 8192; three launches beyond.
     void convolve(std::complex<real_t> *device_data, const std::complex<real_t> *device_h, std::uint64_t batch,
                   void *stream = nullptr)
     {

@@ -1006,9 +1006,10 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
 {
     if (p->path == PATH_FFT4096 && p->variant == 0)
         return launch_fft4096_conv_f32(data, p->twt, h, batch, stream);
-    // N = 8192 / 16384 / 32768, radix-2 stages: both transforms and the multiply in the registers-resident kernel (fft_big.hip)
+    // N = 8192 / 16384 / 32768 radix-2 stages, N = 16384 radix-4 stages: both transforms and the multiply in the
+    // registers-resident kernel (fft_big.hip)
     if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode &&
-        p->radix == 2 && p->twt_big && fft_big_supports(p->n, p->radix)) {
+        (p->radix == 2 || big_is_default(p->n, p->radix)) && p->twt_big && fft_big_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_big;

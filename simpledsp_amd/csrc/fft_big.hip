@@ -61,7 +61,7 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // R4 (N = 16384 = 4^7 only): the fourteen layers run as seven radix-4 DIF stages (fft32_r4.h) -- two stages, then half of the
 // third in pass A; its other half and two stages in pass B; two stages in pass C -- with their own thread-twiddle table
 // (capi.hip: upload_thread_twiddles_big_r4); loads, exchanges and the store are the same.
-// CONV (forward radix-2 plans): the fused fast convolution data <- IFFT(FFT(data) .* h) of SURVEY 8(f)-1.  The forward
+// CONV (forward plans): the fused fast convolution data <- IFFT(FFT(data) .* h) of SURVEY 8(f)-1.  The forward
 // transform leaves register i holding X[t + T * bit_reverse5(i)]; multiplied by h there (rows of h through a buffer resource,
 // default cache policy: every workgroup reads the same N points) and RENAMED z[bit_reverse5(i)] = x[i], that is the input
 // layout of pass A, so the reverse transform (conjugated table values, +i rotations, 1/N at the store) runs on the same
@@ -70,7 +70,7 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false>
 __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                        float scale, uint64_t batch, const float2 *__restrict__ h)
 {
-    static_assert(!CONV || (!REV && !R4), "the fused convolution belongs to forward plans of radix-2 stages");
+    static_assert(!CONV || !REV, "the fused convolution belongs to forward plans");
     static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
@@ -113,15 +113,21 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     // CJ: the table holds the other direction's thread twiddles; AGAIN: the LDS plane may still be read by the transform before
     auto transform = [&](float2 (&y)[32], auto rev_tag, auto conj_tag, auto again_tag) {
         constexpr bool RV = decltype(rev_tag)::value, CJ = decltype(conj_tag)::value, AGAIN = decltype(again_tag)::value;
+        [[maybe_unused]] auto tab = [&](int slot) { // radix-4 form: the thread's value of a table slot
+            float2 wv = tw[slot * T + t];
+            if constexpr (CJ)
+                wv.y = -wv.y;
+            return wv;
+        };
         if constexpr (R4) {
             float2 thr[3];
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                thr[q] = tw[q * T + t]; // W_N^((q + 1) t)
+                thr[q] = tab(q); // W_N^((q + 1) t)
             r4_stage<RV, 4, 7, 2, true>(y, thr); // stage 0: quarter = register bits 4, 3; constant W_32^(q (k & 7))
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                thr[q] = tw[(3 + q) * T + t]; // W_4096^((q + 1) t)
+                thr[q] = tab(3 + q); // W_4096^((q + 1) t)
             r4_stage<RV, 2, 1, 8, true>(y, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
             // stage 2, first layer: register bit 0 is index bit 9, index bit 8 is the thread's: the quarter (1, 1) = odd
             // registers of the threads t >= 256
@@ -160,15 +166,15 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
 
         if constexpr (R4) {
             layer<16>(y); // stage 2, second layer: register bit 4 is index bit 8
-            r4_split_twiddles<RV>(y, (blk & 1u) != 0, tw[6 * T + t], tw[7 * T + t], std::make_integer_sequence<int, 32>{});
+            r4_split_twiddles<RV>(y, (blk & 1u) != 0, tab(6), tab(7), std::make_integer_sequence<int, 32>{});
             float2 thr[3];
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                thr[q] = tw[(8 + q) * T + t]; // W_256^((q + 1) v)
+                thr[q] = tab(8 + q); // W_256^((q + 1) v)
             r4_stage<RV, 3, 3, 4, true>(y, thr); // stage 3: register bits 3, 2; constant W_16^(q (j & 3))
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                thr[q] = tw[(11 + q) * T + t]; // W_64^((q + 1) v)
+                thr[q] = tab(11 + q); // W_64^((q + 1) v)
             r4_stage<RV, 1, 0, 0, true>(y, thr); // stage 4: register bits 1, 0; thread twiddles only
         } else {
             fft32_dif<RV, true, 0, true, CJ>(y, tw + 5 * T + t, T);
@@ -257,8 +263,14 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false> int laun
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
     if (a.real_mode == 3) { // fused convolution (forward radix-2 plans): a.tw2 = h
-        if (a.reverse || a.radix != 2 || !a.tw2)
-            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big convolution: forward radix-2 plan and a filter spectrum needed");
+        if (a.reverse || !a.tw2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big convolution: forward plan and a filter spectrum needed");
+        if constexpr (L == 14) {
+            if (a.radix == 4) // a.tw: the radix-4 table
+                return launch_l<L, false, true, true, true>(a, s);
+        }
+        if (a.radix != 2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big convolution: radix-2 stages (radix-4 stages at N = 16384)");
         return launch_l<L, false, true, false, true>(a, s);
     }
     if constexpr (L == 14) {
