@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import simpledsp_amd as sd
 
-for n_real in (1024, 8192):
+for n_real in ([int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else (1024, 8192)):
     batch = (1 << 28) // n_real  # 1 GiB of float32
     x = torch.randn((batch, n_real), device="cuda")
     fwd, inv = sd.RfftPlan(n_real, 2, sd.forward_fft, batch), sd.RfftPlan(n_real, 2, sd.reverse_fft, batch)
