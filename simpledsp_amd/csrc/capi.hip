@@ -391,6 +391,24 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_big_f32(a, stream);
     }
 
+    // real-input plans of n_real = 16384 / 32768 (N = 8192 / 16384 complex), radix-2 stages: split / merge inside the
+    // registers-resident kernel (fft_big.hip, REAL); variants 1 / 2 keep the register-pass family's MODE 1 / 2
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->real_mode && p->radix == 2 && p->twt_big &&
+        fft_big_supports(p->n, p->radix)) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->twt_big;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = (float)(1.0 / p->n);
+        a.reverse = rev;
+        a.nontemporal = 1;
+        a.real_mode = p->real_mode;
+        a.tw2 = p->tw2;
+        return launch_fft_big_f32(a, stream);
+    }
+
     const bool wave64 = p->path == PATH_REG && p->precision == SDSP_HIP_F64 && !p->real_mode && fft_wave_supports(p->n, p->radix);
     if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && (variant == 0 || (variant == 1 && wave64))) {
         fft_reg_args a;
@@ -1113,7 +1131,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = "sdsp_fft1024_wave";
     if (p->path == PATH_REG && p->variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
         name = "sdsp_fft_wave_f32";
-    if (big)
+    if (big || (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->real_mode && p->radix == 2 &&
+                p->twt_big && fft_big_supports(p->n, p->radix)))
         name = "sdsp_fft_big_kernel";
     if (mix_size && p->variant == mix_variant)
         name = "sdsp_fft_mix_f32";

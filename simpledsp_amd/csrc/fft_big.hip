@@ -66,11 +66,19 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // default cache policy: every workgroup reads the same N points) and RENAMED z[bit_reverse5(i)] = x[i], that is the input
 // layout of pass A, so the reverse transform (conjugated table values, +i rotations, 1/N at the store) runs on the same
 // registers and the same LDS plane: one HBM read and one write per element instead of three of each.
-template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false>
+// REAL (radix-2 plans): real-input packing, SURVEY 8(f)-3 -- the buffer holds 2N reals per transform, read as N complex.
+// 1 (forward plans): split after the transform, X[k] from Z[k] and Z[N-k]; 2 (reverse plans): merge before it; h = W_2N^j,
+// direction-folded (the formulas are fft_reg.hip's MODE 1 / 2).  Element k = t + T b and its partner N - k = (T - t) + T (31 - b)
+// sit in different threads, so the pairs meet in LDS: the elements with b < 16 are parked as float2 in slot k, the owner of
+// N - k (b >= 16) reads its partner there, computes BOTH results of the pair, keeps its own and puts the other back into the
+// same slot, and the parked side reads its results back -- 64 ds_*_b64 per thread and no second copy of the data in registers.
+// k = 0 and k = N/2 (thread 0) pair with nobody.
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0>
 __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                        float scale, uint64_t batch, const float2 *__restrict__ h)
 {
     static_assert(!CONV || !REV, "the fused convolution belongs to forward plans");
+    static_assert(REAL == 0 || (!R4 && !CONV && (REAL == 1) == !REV), "real-input packing: radix-2 stages; split forward, merge reverse");
     static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
@@ -212,7 +220,70 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     using yes = std::true_type;
     using no = std::false_type;
 
-    transform(x, std::integral_constant<bool, REV>{}, no{}, no{});
+    // real-input packing: register r holds element k = t + T b(r), b(r) = r before the transform, bit_reverse5(r) after it
+    [[maybe_unused]] auto real_pairs = [&](float2 (&y)[32], auto merge_tag, auto after_tag) {
+        constexpr bool MERGE = decltype(merge_tag)::value, AFTER = decltype(after_tag)::value;
+        auto lds_f2 = [&](uint32_t byte) -> float2 & { return *reinterpret_cast<float2 *>(sdsp_fft_big_smem + byte); };
+        const __amdgpu_buffer_rsrc_t wrows = make_rows(h, 2 * N * sizeof(float2)); // W_2N^j, j < 2N
+        if constexpr (AFTER)
+            __syncthreads(); // every wave has read the transform's last plane
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+            if (b < 16)
+                lds_f2(8u * t + 8u * T * b) = y[r];
+        }
+        __syncthreads();
+        const bool t0 = t == 0;
+        const uint32_t pbase = 8u * (T - t); // partner of (t, b): slot (T - t) + T (31 - b) = N - k
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+            if (b < 16)
+                continue;
+            const float2 pa = lds_f2(pbase + 8u * T * (31 - b));                 // element a = N - k
+            const float2 w = row_load<false>(wrows, pbase, 8u * T * (31 - b));   // W_2N^a
+            const float2 own = y[r];
+            const float2 e = float2{ 0.5f * (pa.x + own.x), 0.5f * (pa.y - own.y) }; // (A + conj B) / 2
+            const float2 d = float2{ 0.5f * (pa.x - own.x), 0.5f * (pa.y + own.y) }; // (A - conj B) / 2
+            const float2 wd = cmul(d, w);
+            float2 ra, rb;
+            if constexpr (MERGE) { // Z[a] = E + i O, Z[N-a] = conj(E - i O)
+                ra = float2{ e.x - wd.y, e.y + wd.x };
+                rb = float2{ e.x + wd.y, wd.x - e.y };
+            } else { // X[a] = E + T, X[N-a] = conj(E - T), T = -i W D
+                ra = float2{ e.x + wd.y, e.y - wd.x };
+                rb = float2{ e.x - wd.y, -wd.x - e.y };
+            }
+            if (b == 16) { // k = N/2 in thread 0: conj, no partner (the slot it touched is the padding behind the plane)
+                rb.x = t0 ? own.x : rb.x;
+                rb.y = t0 ? -own.y : rb.y;
+            }
+            y[r] = rb;
+            lds_f2(pbase + 8u * T * (31 - b)) = ra;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+            if (b >= 16)
+                continue;
+            float2 v = lds_f2(8u * t + 8u * T * b);
+            if (b == 0) { // k = 0 in thread 0: (X[0], X[N]) packed, both real
+                const float2 z = v;
+                const float2 p0 = MERGE ? float2{ 0.5f * (z.x + z.y), 0.5f * (z.x - z.y) } : float2{ z.x + z.y, z.x - z.y };
+                v.x = t0 ? p0.x : v.x;
+                v.y = t0 ? p0.y : v.y;
+            }
+            y[r] = v;
+        }
+    };
+
+    if constexpr (REAL == 2)
+        real_pairs(x, yes{}, no{});
+    transform(x, std::integral_constant<bool, REV>{}, no{}, std::integral_constant<bool, REAL == 2>{});
+    if constexpr (REAL == 1)
+        real_pairs(x, no{}, yes{});
 
     if constexpr (CONV) {
         // x[i] = X[t + T * bit_reverse5(i)]: times h there, renamed into pass A's input order (no data moves: a renaming)
@@ -241,10 +312,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     }
 }
 
-template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false> int launch_l(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
-    constexpr size_t lds = sizeof(float) << L;
-    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4, CONV>;
+    constexpr size_t lds = (sizeof(float) << L) + (REAL ? 8 : 0); // real-input pairs: one float2 of padding behind the plane
+    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4, CONV, REAL>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
@@ -262,6 +333,15 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false> int laun
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
+    if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: a.tw2 = W_2N^j
+        if (a.radix != 2 || !a.tw2 || (a.real_mode == 1) != !a.reverse)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: radix-2 plan, split forward / merge reverse");
+        if constexpr (L <= 14) { // n_real = 16384 / 32768 (the API stops there)
+            return a.reverse ? launch_l<L, true, true, false, false, 2>(a, s) : launch_l<L, false, true, false, false, 1>(a, s);
+        } else {
+            return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real <= 32768");
+        }
+    }
     if (a.real_mode == 3) { // fused convolution (forward radix-2 plans): a.tw2 = h
         if (a.reverse || !a.tw2)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big convolution: forward plan and a filter spectrum needed");
