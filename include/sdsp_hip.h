@@ -147,7 +147,7 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *plan, void *data, const void *h, ui
  *     transform would give), out[0] = (X[0], X[n_real/2]) -- both are real; the upper half of the
  *     spectrum is the conjugate mirror.
  *   direction REVERSE: the inverse of that (packed half spectrum in, real samples out, 1/N scaled).
- * f32; radix 2: n_real = 32 .. 32768 a power of 2; radix 4: n_real/2 a power of 4.  Use the plan
+ * f32; radix 2: n_real = 32 .. 65536 a power of 2; radix 4: n_real/2 a power of 4, n_real <= 32768.  Use the plan
  * with sdsp_hip_fft_exec / _exec_host (batch counts transforms).
  */
 int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction,

@@ -391,10 +391,10 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return launch_fft_big_f32(a, stream);
     }
 
-    // real-input plans of n_real = 16384 / 32768 (N = 8192 / 16384 complex), radix-2 stages: split / merge inside the
+    // real-input plans of n_real = 8192 .. 65536 (N = 4096 .. 32768 complex), radix-2 stages: split / merge inside the
     // registers-resident kernel (fft_big.hip, REAL); variants 1 / 2 keep the register-pass family's MODE 1 / 2
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->real_mode && p->radix == 2 && p->twt_big &&
-        fft_big_supports(p->n, p->radix)) {
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->real_mode && p->twt_big &&
+        fft_big_real_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_big;
@@ -862,14 +862,22 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT radix 4 size must be a power of 4! (n_real / 2)");
     if (radix != 2 && radix != 4)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix must be 2 or 4");
-    if (precision == SDSP_HIP_F32 ? !fft_reg_supports(n, radix) : !fft_reg64_supports(n, radix))
-        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768 (f32) / 32 .. 16384 (f64)");
+    const bool big_real = precision == SDSP_HIP_F32 && fft_big_real_supports(n, radix); // fft_big.hip, REAL
+    if (!big_real && (precision == SDSP_HIP_F32 ? !fft_reg_supports(n, radix) : !fft_reg64_supports(n, radix)))
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768 (f32; radix 2: .. 65536) / 32 .. 16384 (f64)");
     sdsp_hip_fft_plan *p = nullptr;
     if (int rc = sdsp_hip_fft_plan_create(&p, n, radix, direction, precision, max_batch, device))
         return rc;
     p->path = PATH_REG; // also at n = 4096 f32 (the tuned complex kernels have no split stage)
     p->real_mode = direction == SDSP_HIP_FORWARD ? 1 : 2;
     std::vector<double> w;
+    if (big_real && !p->twt_big) { // n = 4096: the complex plan has no use for fft_big.hip's table
+        make_twiddles(n, direction, w);
+        if (int rc = upload_thread_twiddles_big(w, n, &p->twt_big)) {
+            sdsp_hip_fft_plan_destroy(p);
+            return rc;
+        }
+    }
     make_twiddles(n_real, direction, w);
     if (int rc = upload_twiddles(w, precision, &p->tw2)) {
         sdsp_hip_fft_plan_destroy(p);
@@ -1131,8 +1139,8 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
         name = "sdsp_fft1024_wave";
     if (p->path == PATH_REG && p->variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
         name = "sdsp_fft_wave_f32";
-    if (big || (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->real_mode && p->radix == 2 &&
-                p->twt_big && fft_big_supports(p->n, p->radix)))
+    if (big || (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->real_mode && p->twt_big &&
+                fft_big_real_supports(p->n, p->radix)))
         name = "sdsp_fft_big_kernel";
     if (mix_size && p->variant == mix_variant)
         name = "sdsp_fft_mix_f32";

@@ -336,11 +336,7 @@ template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
     if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: a.tw2 = W_2N^j
         if (a.radix != 2 || !a.tw2 || (a.real_mode == 1) != !a.reverse)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: radix-2 plan, split forward / merge reverse");
-        if constexpr (L <= 14) { // n_real = 16384 / 32768 (the API stops there)
-            return a.reverse ? launch_l<L, true, true, false, false, 2>(a, s) : launch_l<L, false, true, false, false, 1>(a, s);
-        } else {
-            return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real <= 32768");
-        }
+        return a.reverse ? launch_l<L, true, true, false, false, 2>(a, s) : launch_l<L, false, true, false, false, 1>(a, s);
     }
     if (a.real_mode == 3) { // fused convolution (forward radix-2 plans): a.tw2 = h
         if (a.reverse || !a.tw2)
@@ -372,12 +368,19 @@ bool fft_big_supports(uint32_t n, int radix)
     return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
 }
 
+// real-input plans (radix 2): n_real = 8192 .. 65536
+bool fft_big_real_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384 || n == 32768); }
+
 int launch_fft_big_f32(const fft_reg_args &a, void *stream)
 {
     if (a.batch == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (a.n) {
+    case 4096: // real-input plans of n_real = 8192 only (the complex transform has its own kernels)
+        if (a.real_mode != 1 && a.real_mode != 2)
+            break;
+        return launch_dir<12>(a, s);
     case 8192: return launch_dir<13>(a, s);
     case 16384: return launch_dir<14>(a, s);
     case 32768: return launch_dir<15>(a, s);
