@@ -777,7 +777,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc && ((precision == SDSP_HIP_F32 && fft_reg_supports(n, radix)) ||
                     (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))))
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
-        if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
+        if (!rc && precision == SDSP_HIP_F32 && (fft_big_supports(n, radix) || fft_big_conv_supports(n, radix)))
             rc = big_is_default(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
             rc = upload_thread_twiddles_wave(w, n, radix, &p->twt_wave);
@@ -871,7 +871,7 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
     p->path = PATH_REG; // also at n = 4096 f32 (the tuned complex kernels have no split stage)
     p->real_mode = direction == SDSP_HIP_FORWARD ? 1 : 2;
     std::vector<double> w;
-    if (big_real && !p->twt_big) { // n = 4096: the complex plan has no use for fft_big.hip's table
+    if (big_real && !p->twt_big) { // (every complex plan this kernel serves has the table already)
         make_twiddles(n, direction, w);
         if (int rc = upload_thread_twiddles_big(w, n, &p->twt_big)) {
             sdsp_hip_fft_plan_destroy(p);
@@ -1035,7 +1035,7 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
     // N = 8192 / 16384 / 32768 radix-2 stages, N = 16384 radix-4 stages: both transforms and the multiply in the
     // registers-resident kernel (fft_big.hip)
     if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && p->variant == 0 && !p->real_mode &&
-        (p->radix == 2 || big_is_default(p->n, p->radix)) && p->twt_big && fft_big_supports(p->n, p->radix)) {
+        p->twt_big && fft_big_conv_supports(p->n, p->radix)) {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_big;

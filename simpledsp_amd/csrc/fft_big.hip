@@ -368,8 +368,12 @@ bool fft_big_supports(uint32_t n, int radix)
     return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
 }
 
-// real-input plans (radix 2): n_real = 8192 .. 65536
-bool fft_big_real_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384 || n == 32768); }
+// real-input plans (radix 2): n_real = 4096 .. 65536; fused convolution: the same sizes, and the radix-4 form at N = 16384
+bool fft_big_real_supports(uint32_t n, int radix)
+{
+    return radix == 2 && (n == 2048 || n == 4096 || n == 8192 || n == 16384 || n == 32768);
+}
+bool fft_big_conv_supports(uint32_t n, int radix) { return fft_big_real_supports(n, radix) || (radix == 4 && n == 16384); }
 
 int launch_fft_big_f32(const fft_reg_args &a, void *stream)
 {
@@ -377,8 +381,12 @@ int launch_fft_big_f32(const fft_reg_args &a, void *stream)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (a.n) {
-    case 4096: // real-input plans of n_real = 8192 only (the complex transform has its own kernels)
-        if (a.real_mode != 1 && a.real_mode != 2)
+    case 2048: // real-input plans (n_real = 4096) and the fused convolution only: the complex transform has its own kernels
+        if (a.real_mode == 0)
+            break;
+        return launch_dir<11>(a, s);
+    case 4096: // likewise (n_real = 8192)
+        if (a.real_mode == 0)
             break;
         return launch_dir<12>(a, s);
     case 8192: return launch_dir<13>(a, s);

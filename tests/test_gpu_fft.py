@@ -440,7 +440,7 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
     fused = n <= (16384 if prec == sd.F32 else 8192) or (prec == sd.F32 and radix == 2 and n == 1 << 15)
     # two fused forms: the one-wave kernel, or (radix 2, N = 8192 / 16384) the registers-resident kernel of csrc/fft_big.hip, + the
     # register-pass MODE 3 as variant 2
-    two_fused = prec == sd.F32 and (n in (256, 1024, 16384) or (radix == 2 and n in (512, 2048, 8192)))
+    two_fused = prec == sd.F32 and (n in (256, 1024, 16384) or (radix == 2 and n in (512, 2048, 4096, 8192)))
     for variant in ((0, 1, 2) if two_fused else (0, 1) if fused else (0,)):
         plan.set_variant(variant)  # f32 n <= 16384 (radix 2: 32768), f64 n <= 8192: 0 = fused single kernel, 1 = three launches
         d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
@@ -495,7 +495,7 @@ def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precis
     wave = not f64 and (half == 256 or (radix == 2 and half in (512, 1024)))  # where the wave kernels measured faster (capi.hip)
     # f32, radix 2, n_real / 2 = 8192 / 16384: split / merge inside the registers-resident kernel (csrc/fft_big.hip, REAL: the pairs
     # meet in LDS); variant 1 the register-pass family's, as above
-    big = not f64 and radix == 2 and half in (4096, 8192, 16384, 32768)
+    big = not f64 and radix == 2 and half in (2048, 4096, 8192, 16384, 32768)
     assert fwd.info.kernel.decode() == ("sdsp_fft1024_wave" if wave and half == 1024 else "sdsp_fft_wave_f32" if wave else
                                         "sdsp_fft_big_kernel" if big else
                                         "sdsp_fft_reg_f64_kernel" if f64 else "sdsp_fft_reg_kernel")
