@@ -78,7 +78,7 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
                                                                        float scale, uint64_t batch, const float2 *__restrict__ h)
 {
     static_assert(!CONV || !REV, "the fused convolution belongs to forward plans");
-    static_assert(REAL == 0 || (!R4 && !CONV && (REAL == 1) == !REV), "real-input packing: radix-2 stages; split forward, merge reverse");
+    static_assert(REAL == 0 || (!CONV && (REAL == 1) == !REV), "real-input packing: split forward, merge reverse");
     static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
@@ -334,8 +334,14 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
 {
     if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: a.tw2 = W_2N^j
-        if (a.radix != 2 || !a.tw2 || (a.real_mode == 1) != !a.reverse)
-            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: radix-2 plan, split forward / merge reverse");
+        if (!a.tw2 || (a.real_mode == 1) != !a.reverse)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: split forward / merge reverse, W_2N needed");
+        if constexpr (L == 14) {
+            if (a.radix == 4) // a.tw: the radix-4 table
+                return a.reverse ? launch_l<L, true, true, true, false, 2>(a, s) : launch_l<L, false, true, true, false, 1>(a, s);
+        }
+        if (a.radix != 2)
+            return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: radix-2 stages (radix-4 stages at N = 16384)");
         return a.reverse ? launch_l<L, true, true, false, false, 2>(a, s) : launch_l<L, false, true, false, false, 1>(a, s);
     }
     if (a.real_mode == 3) { // fused convolution (forward radix-2 plans): a.tw2 = h
@@ -368,12 +374,12 @@ bool fft_big_supports(uint32_t n, int radix)
     return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
 }
 
-// real-input plans (radix 2): n_real = 4096 .. 65536; fused convolution: the same sizes, and the radix-4 form at N = 16384
+// real-input plans (n = n_real / 2) and the fused convolution: radix-2 stages n = 2048 .. 32768, radix-4 stages n = 16384
 bool fft_big_real_supports(uint32_t n, int radix)
 {
-    return radix == 2 && (n == 2048 || n == 4096 || n == 8192 || n == 16384 || n == 32768);
+    return (radix == 2 && (n == 2048 || n == 4096 || n == 8192 || n == 16384 || n == 32768)) || (radix == 4 && n == 16384);
 }
-bool fft_big_conv_supports(uint32_t n, int radix) { return fft_big_real_supports(n, radix) || (radix == 4 && n == 16384); }
+bool fft_big_conv_supports(uint32_t n, int radix) { return fft_big_real_supports(n, radix); }
 
 int launch_fft_big_f32(const fft_reg_args &a, void *stream)
 {
