@@ -4,6 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft4096|fft1m|iir|iir64|iir_mix|iir_lp|iir_il]
     python bench.py --workload fft --n 8192 --radix 2 [--precision f64]     (any covered size; not a BASELINE config)
     python bench.py --workload fir --taps 32                                  (FIR bank; not a BASELINE config)
+    python bench.py --workload conv --n 8192 --radix 2 | --workload rfft --n 16384   (not BASELINE configs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -19,7 +20,9 @@ At N = 1 the default run then measures the other single-GPU BASELINE configs wit
 them to the SAME JSON line as `"other_configs": [{config, metric, value, unit, dtype, ms_per_step, roofline, cpu_baseline}]`:
 configs[2] (N = 2^20, batch 256), configs[3] (biquad bank 1M x 4096: f32, f64, and the numerator-folded LP class,
 testIIR.cpp:465-494) and one configs[4] shard (262144 transforms = 8 GiB) on this one GPU.  `--no-other-configs`
-skips them.  With N > 1 the per-GPU shard is configs[4]'s 262144 transforms.
+skips them.  With N > 1 the per-GPU shard is configs[4]'s 262144 transforms.  The default run also appends `"extras"`: the
+sizes next to the headline (N = 8192 / 16384 / 32768) and SURVEY 8(f) rows (fused convolution, real-input packing) on 1 GiB
+each, same K / W, each with its roofline object -- not BASELINE configs, no CPU leg (`--no-extras` skips them).
 
 `roofline.achieved` = algorithmic bytes per launch (each element read once + written
 once) / average launch duration measured with HIP events on the launch stream inside this run.
@@ -47,8 +50,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_mix", "iir_il", "fft", "fir"])
-    ap.add_argument("--n", type=int, default=1024, help="--workload fft: transform size")
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_mix", "iir_il", "fft", "fir", "conv", "rfft"])
+    ap.add_argument("--n", type=int, default=1024, help="--workload fft / conv: transform size; rfft: n_real")
     ap.add_argument("--radix", type=int, default=2, help="--workload fft: 2 or 4")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / fir")
     ap.add_argument("--taps", type=int, default=32, help="--workload fir: filter length")
@@ -59,6 +62,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-other-configs", action="store_true", help="headline workload only")
+    ap.add_argument("--no-extras", action="store_true", help="skip the SURVEY 8(f) rows / neighbouring sizes appended as \"extras\"")
     ap.add_argument("--other-cpu-seconds", type=float, default=3.0, help="CPU leg of each other_configs entry")
     return ap.parse_args()
 
@@ -144,6 +148,54 @@ def make_fft(sd, torch, dev, args):
     }
     return (step, batch, int(info.algorithmic_bytes), desc,
             f"batched complex FFTs/sec (N={n}, radix-{args.radix}, {args.precision})", "FFT/s", args.precision, (fwd, rev, x))
+
+
+def make_conv(sd, torch, dev, args):
+    """fused fast convolution data <- IFFT(FFT(data) .* h), SURVEY 8(f)-1 (not a BASELINE config): 1 GiB of transforms;
+    |h[k]| = 1 (random phases) keeps the in-place data finite over any number of steps"""
+    n = args.n
+    batch = args.batch_per_gpu or max(1, (1 << 27) // n)
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 6 + dev.index)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device=dev))
+    ph = torch.rand((n,), generator=g, device=dev) * 6.283185307179586
+    h = torch.polar(torch.ones_like(ph), ph)
+    plan = sd.FftPlan(n, args.radix, sd.forward_fft, sd.F32, max_batch=batch, device=dev.index)
+
+    def step():
+        plan.convolve(x, h)
+
+    info = plan.info
+    desc = {
+        "workload": f"fused fast convolution N={n} radix-{args.radix} (forward, multiply, reverse in one kernel), in place, f32 "
+                    "(SURVEY 8(f)-1, not a BASELINE config)",
+        "n": n, "radix": args.radix, "batch_per_gpu": batch, "kernel": "fused convolution of " + info.kernel.decode(), "hbm_passes": 1,
+    }
+    return (step, batch, int(info.algorithmic_bytes), desc, f"fast convolutions/sec (N={n}, radix-{args.radix}, f32)", "convolutions/s",
+            "f32", (plan, x, h))
+
+
+def make_rfft(sd, torch, dev, args):
+    """real-input packing, SURVEY 8(f)-3 (not a BASELINE config): 1 GiB of real samples, forward / inverse alternating"""
+    n_real = args.n
+    batch = args.batch_per_gpu or max(1, (1 << 28) // n_real)
+    g = torch.Generator(device=dev).manual_seed(0x5D5B + 7 + dev.index)
+    x = torch.randn((batch, n_real), generator=g, device=dev)
+    fwd = sd.RfftPlan(n_real, args.radix, sd.forward_fft, max_batch=batch, device=dev.index)
+    inv = sd.RfftPlan(n_real, args.radix, sd.reverse_fft, max_batch=batch, device=dev.index)
+    state = {"i": 0}
+
+    def step():
+        (fwd if state["i"] % 2 == 0 else inv).exec(x)
+        state["i"] += 1
+
+    info = fwd.info
+    desc = {
+        "workload": f"real-input FFT n_real={n_real} radix-{args.radix} (packed half spectrum, in place), f32, forward/inverse alternating "
+                    "(SURVEY 8(f)-3, not a BASELINE config)",
+        "n_real": n_real, "radix": args.radix, "batch_per_gpu": batch, "kernel": info.kernel.decode(), "hbm_passes": 1,
+    }
+    return (step, batch, int(info.algorithmic_bytes), desc, f"real-input FFTs/sec (n_real={n_real}, radix-{args.radix}, f32)", "FFT/s",
+            "f32", (fwd, inv, x))
 
 
 def make_fir(sd, torch, dev, args):
@@ -299,6 +351,7 @@ WORKLOADS = {
     "iir_lp": lambda *a: make_iir(*a, lp_class=True),
     "iir_mix": lambda *a: make_iir(*a, mixed=True),
     "iir_il": lambda *a: make_iir(*a, interleaved=True), "fft": make_fft, "fir": make_fir,
+    "conv": make_conv, "rfft": make_rfft,
 }
 
 
@@ -336,7 +389,7 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
     launches = 1
     piece = sd.get_launch_piece_bytes()
     buf_bytes = units * unit_bytes // 2  # in place: every byte of the buffer is read once and written once
-    if piece and name in ("fft4096", "fft") and desc.get("hbm_passes") == 1 and desc.get("n", 4096) <= 8192 and buf_bytes > piece + piece // 2:
+    if piece and name in ("fft4096", "fft", "conv") and desc.get("hbm_passes") == 1 and desc.get("n", 4096) <= 8192 and buf_bytes > piece + piece // 2:
         launches = -(-units // max(256, piece // (unit_bytes // 2) // 256 * 256))
     kern_ms = step_ms / launches
     world = args.world
@@ -400,6 +453,19 @@ def main():
             others.append((name, r))
         args.batch_per_gpu = 0
 
+    # not BASELINE configs: the SURVEY 8(f) rows and the sizes next to the headline, same K / W, appended as "extras" so that a
+    # fresh-box run carries their numbers too (1 GiB each; no CPU leg)
+    extras = []
+    if world == 1 and args.workload == "fft4096" and not args.no_other_configs and not args.no_extras and not args.batch_per_gpu and args.variant < 0:
+        keep_n, keep_radix = args.n, args.radix
+        for name, n, radix in (("fft", 8192, 0), ("fft", 16384, 2), ("fft", 16384, 4), ("fft", 32768, 2), ("conv", 4096, 4), ("conv", 8192, 2),
+                               ("rfft", 16384, 2), ("rfft", 32768, 2)):
+            args.n, args.radix = n, radix
+            r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
+            r["steps"], r["warmup"] = args.steps, args.warmup
+            extras.append(r)
+        args.n, args.radix = keep_n, keep_radix
+
     if rank == 0:
         out = {
             "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps,
@@ -408,7 +474,7 @@ def main():
             "config": head["config"], "roofline": head["roofline"],
         }
         # the extra workloads (--workload fft / fir) are not BASELINE configs: no CPU leg for them
-        if world == 1 and not args.no_cpu_baseline and args.workload not in ("fft", "fir"):
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ("fft", "fir", "conv", "rfft"):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if out["cpu_baseline"]["value"]:
                 out["cpu_baseline"]["gpu_over_cpu"] = head["value"] / out["cpu_baseline"]["value"]
@@ -425,6 +491,8 @@ def main():
                     if r["cpu_baseline"]["value"]:
                         r["cpu_baseline"]["gpu_over_cpu"] = r["value"] / r["cpu_baseline"]["value"]
                 out["other_configs"].append(r)
+        if extras:
+            out["extras"] = extras
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
