@@ -1,12 +1,15 @@
-// fft_big.hip -- batched N = 8192 / 16384 / 32768 complex f32 FFT with radix-2 butterfly stages
-// (sdsp::fft_radix2, fft.h:258-299) in ONE pass over HBM, for gfx950.
+// fft_big.hip -- the registers-resident single-pass FFT kernel for gfx950, f32:
+//   * batched N = 8192 / 16384 / 32768 complex transforms with radix-2 butterfly stages (sdsp::fft_radix2, fft.h:258-299), and
+//     N = 16384 = 4^7 with seven radix-4 stages (sdsp::fft_radix4, fft.h:301-360; fft32_r4.h);
+//   * the fused fast convolution of SURVEY 8(f)-1 (CONV) and the real-input packing of SURVEY 8(f)-3 (REAL) for N = 2048 .. 32768.
 //
 // These sizes are too large for the register-pass family's "whole tile in LDS" scheme to keep more
 // than one workgroup on a CU (N = 16384 is 128 KiB of complex f32), so nothing overlapped the load and
-// store phases there (44-51 % of HBM peak; this kernel: 73-76 % at 8192, 69 % at 16384, 56 % at 32768 --
+// store phases there (44-51 % of HBM peak; this kernel: 71-77 % at 8192, 69-71 % at 16384, 56 % at 32768 --
 // where the previous path was the two-pass four-step).  In-place read+write traffic plateaus at 74-77 % of
 // 8 TB/s on this part whatever the shape (tools/delaybench.hip), and a CU that holds two workgroups of 128 KiB / one of
-// 256 KiB caps at ~70 % / ~65 % even with no arithmetic between the loads and the stores (tools/cucap.hip).  Here the transform lives in REGISTERS, 32 points per
+// 256 KiB caps at ~70 % / ~65 % even with no arithmetic between the loads and the stores (tools/cucap.hip).
+// Here the transform lives in REGISTERS, 32 points per
 // thread (N/32 threads per transform, one transform per workgroup), and LDS is only the exchange medium
 // between register passes -- moved one plane (real, then imaginary) at a time, so a transform needs
 // 4*N bytes of LDS and TWO workgroups of N = 16384 (four of N = 8192) share a CU:
@@ -66,7 +69,7 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // default cache policy: every workgroup reads the same N points) and RENAMED z[bit_reverse5(i)] = x[i], that is the input
 // layout of pass A, so the reverse transform (conjugated table values, +i rotations, 1/N at the store) runs on the same
 // registers and the same LDS plane: one HBM read and one write per element instead of three of each.
-// REAL (radix-2 plans): real-input packing, SURVEY 8(f)-3 -- the buffer holds 2N reals per transform, read as N complex.
+// REAL: real-input packing, SURVEY 8(f)-3 -- the buffer holds 2N reals per transform, read as N complex.
 // 1 (forward plans): split after the transform, X[k] from Z[k] and Z[N-k]; 2 (reverse plans): merge before it; h = W_2N^j,
 // direction-folded (the formulas are fft_reg.hip's MODE 1 / 2).  Element k = t + T b and its partner N - k = (T - t) + T (31 - b)
 // sit in different threads, so the pairs meet in LDS: the elements with b < 16 are parked as float2 in slot k, the owner of
