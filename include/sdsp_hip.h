@@ -193,7 +193,7 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *plan, sdsp_hip_fft_plan_
 int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out);
 /* choose among kernel variants of a plan (tuning/testing).  Variant 0 is the default; a plan has at most two documented
  * alternates (same transform, same tolerance; DESIGN.md section 5 lists them per size: e.g. n = 4096 radix 4: 1, 2 = other
- * store / barrier schedules of the same kernel; n = 8192 mixed-radix plans: 1 = the radix-2-stage kernel; n = 16384 radix 4: 1 = the fft_mix.hip kernel; n = 2^16 ..
+ * store / barrier schedules of the same kernel; n = 8192 AUTO plans and n = 16384 radix-4 plans: 1 = the fft_mix.hip kernel (mixed radix / leading radix-4 stage); n = 2^16 ..
  * 2^19: 1 = three streaming passes; n = 2^20: 1 = two launches per chunk; n = 256 / 1024 / 2048 f32, whose default is a
  * one-wave kernel (fft_wave.hip): 1, 2 = the register-pass family with the default / streaming cache policy -- also for
  * real-input plans of n_real = 512 / 1024 / 2048 and, as variant 2 of sdsp_hip_fft_convolve, for the fused convolution of

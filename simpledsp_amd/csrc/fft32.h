@@ -146,6 +146,32 @@ __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, u
     }
 }
 
+// the same five stages with the thread twiddles already in registers: w[s] = the stage's W^(u << s).  The caller fetches them
+// ahead of the pass (under the data loads, under an LDS exchange), so the first stage does not wait for an L2 round trip
+template <bool REV> __device__ __forceinline__ void fft32_dif_w(float2 (&x)[32], const float2 (&w)[5])
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int h = 16 >> s;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if ((k & h) != 0)
+                continue;
+            const float2 a = x[k], b = x[k + h];
+            x[k] = a + b;
+            float2 d = a - b;
+            const int e = (k & (h - 1)) << s; // W_32 exponent, 0..15
+            if (e == 8) {
+                d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x };
+            } else if (e != 0) {
+                const float cr = kC32[e], ci = REV ? kS32[e] : -kS32[e];
+                d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
+            }
+            x[k + h] = cmul(d, w[s]);
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t brev5(uint32_t v) { return __brev(v) >> 27; }
 
 } // namespace fft32

@@ -76,7 +76,7 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // N - k (b >= 16) reads its partner there, computes BOTH results of the pair, keeps its own and puts the other back into the
 // same slot, and the parked side reads its results back -- 64 ds_*_b64 per thread and no second copy of the data in registers.
 // k = 0 and k = N/2 (thread 0) pair with nobody.
-template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0>
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0, bool PF = true>
 __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                        float scale, uint64_t batch, const float2 *__restrict__ h)
 {
@@ -96,6 +96,12 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     // the transform's rows (T elements = 2 / 4 / 8 KiB apart) through a buffer resource: fft32.h, make_rows
     const __amdgpu_buffer_rsrc_t rows = make_rows(data + xform * N, N * sizeof(float2));
 
+    float2 wa[5]; // pass A's thread twiddles (radix-2 form), in flight with the data
+    if constexpr (!R4 && PF) {
+#pragma unroll
+        for (int st = 0; st < 5; st++)
+            wa[st] = tw[st * T + t];
+    }
     float2 x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
@@ -122,7 +128,7 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
 
     // the transform on the registers: y[k] = element t + T k  ->  y[i] = result[t + T * bit_reverse5(i)].  RV: its direction;
     // CJ: the table holds the other direction's thread twiddles; AGAIN: the LDS plane may still be read by the transform before
-    auto transform = [&](float2 (&y)[32], auto rev_tag, auto conj_tag, auto again_tag) {
+    auto transform = [&](float2 (&y)[32], const float2 (&wa)[5], auto rev_tag, auto conj_tag, auto again_tag) {
         constexpr bool RV = decltype(rev_tag)::value, CJ = decltype(conj_tag)::value, AGAIN = decltype(again_tag)::value;
         [[maybe_unused]] auto tab = [&](int slot) { // radix-4 form: the thread's value of a table slot
             float2 wv = tw[slot * T + t];
@@ -150,7 +156,22 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
                 y[k] = float2{ upper ? r.x : y[k].x, upper ? r.y : y[k].y };
             }
         } else {
-            fft32_dif<RV, true, 0, true, CJ>(y, tw + t, T); // tw: thread-twiddle table [pass][stage][thread], see capi.hip
+            if constexpr (PF)
+                fft32_dif_w<RV>(y, wa); // wa: pass A's thread twiddles, fetched by the caller under the data loads
+            else
+                fft32_dif<RV, true, 0, true, CJ>(y, tw + t, T);
+        }
+
+        // pass B's thread twiddles are fetched here, under the exchange: behind its barriers the first stage of the pass would
+        // wait for an L2 round trip
+        float2 wb[5];
+        if constexpr (!R4 && PF) {
+#pragma unroll
+            for (int st = 0; st < 5; st++) {
+                wb[st] = tw[(5 + st) * T + t]; // tw: thread-twiddle table [pass][stage][thread], see capi.hip
+                if constexpr (CJ)
+                    wb[st].y = -wb[st].y;
+            }
         }
 
         // ---- exchange A -> B, one plane at a time
@@ -188,7 +209,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
                 thr[q] = tab(11 + q); // W_64^((q + 1) v)
             r4_stage<RV, 1, 0, 0, true>(y, thr); // stage 4: register bits 1, 0; thread twiddles only
         } else {
-            fft32_dif<RV, true, 0, true, CJ>(y, tw + 5 * T + t, T);
+            if constexpr (PF)
+                fft32_dif_w<RV>(y, wb);
+            else
+                fft32_dif<RV, true, 0, true, CJ>(y, tw + 5 * T + t, T);
         }
 
         // ---- exchange B -> C
@@ -284,7 +308,7 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
 
     if constexpr (REAL == 2)
         real_pairs(x, yes{}, no{});
-    transform(x, std::integral_constant<bool, REV>{}, no{}, std::integral_constant<bool, REAL == 2>{});
+    transform(x, wa, std::integral_constant<bool, REV>{}, no{}, std::integral_constant<bool, REAL == 2>{});
     if constexpr (REAL == 1)
         real_pairs(x, no{}, yes{});
 
@@ -297,7 +321,11 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
             const int k = (int)(__brev((uint32_t)i) >> 27);
             z[k] = cmul(x[i], row_load<false>(hrows, toff, T * k * sizeof(float2)));
         }
-        transform(z, yes{}, yes{}, yes{});
+        float2 wc[5]; // the reverse transform's pass A: the conjugates
+#pragma unroll
+        for (int st = 0; st < 5; st++)
+            wc[st] = float2{ wa[st].x, -wa[st].y };
+        transform(z, wc, yes{}, yes{}, yes{});
 #pragma unroll
         for (int i = 0; i < 32; i++)
             x[i] = z[i];
@@ -315,10 +343,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
     }
 }
 
-template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0> int launch_l(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0, bool PF = true> int launch_l2(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = (sizeof(float) << L) + (REAL ? 8 : 0); // real-input pairs: one float2 of padding behind the plane
-    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4, CONV, REAL>;
+    auto kern = sdsp_fft_big_kernel<L, REV, NT, R4, CONV, REAL, PF>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
@@ -332,6 +360,17 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
+}
+
+// PF (the kernel's last template argument): fetch a pass's thread twiddles ahead of it -- pass A's under the data loads, pass
+// B's under the first exchange -- instead of at each stage's start behind the exchange's barriers.  One-process A/B
+// (tools/lab_pf.py history in profiles/r02_fft_big_lab.md): complex N = 8192 +1.2 points, N = 16384 +2.3; N = 32768 -1.2 and the
+// real-input forms -0.4 .. -1.6 (their registers are full: the ten extra live values cost more than the round trip) -- so it is
+// on for the plain radix-2 transforms up to N = 16384 only.
+template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0> int launch_l(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr bool PF = !R4 && !CONV && REAL == 0 && L <= 14;
+    return launch_l2<L, REV, NT, R4, CONV, REAL, PF>(a, s);
 }
 
 template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)

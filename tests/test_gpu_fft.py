@@ -168,8 +168,8 @@ def test_mixed_radix_kernels(sd, torch_cuda, oracle, n, radix, ref_radix, batch)
     pick = sorted({0, batch - 1, batch // 2})
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
-        # (16384, 4): the default is fft_big.hip's radix-4 form and fft_mix.hip variant 1; (8192, AUTO): the other way round
-        first, second = ("sdsp_fft_big_kernel", "sdsp_fft_mix_f32") if n == 16384 else ("sdsp_fft_mix_f32", "sdsp_fft_big_kernel")
+        # the default is csrc/fft_big.hip (radix-4 form at (16384, 4), radix-2 stages at (8192, AUTO)) and csrc/fft_mix.hip variant 1
+        first, second = "sdsp_fft_big_kernel", "sdsp_fft_mix_f32"
         assert plan.info.kernel.decode() == first and plan.info.hbm_passes == 1 and plan.info.radix == ref_radix
         d = torch.from_numpy(x).cuda()
         guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")
