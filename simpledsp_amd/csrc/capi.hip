@@ -198,13 +198,13 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **
     return SDSP_HIP_OK;
 }
 
-// Thread-twiddle table of fft_big.hip's radix-4 form (N = 16384 = 4^7, fft32_r4.h): [slot < 14][thread t < 512].  Slots 0-2:
-// W_N^(q t); 3-5: W_4096^(q t); 6, 7: stage 2's pair for the thread's block parity -- (1, W_1024^(2v)) for an even block,
-// (W_1024^v, W_1024^(3v)) for an odd one; 8-10: W_256^(q v); 11-13: W_64^(q v); q = 1, 2, 3, v = t mod 16, block = t / 16.
+// Thread-twiddle table of fft_big.hip's radix-4 form (N = 16384 = 4^7 and N = 4096 = 4^6, fft32_r4.h): [slot < 14][thread t < N/32].
+// For N = 16384: slots 0-2: W_N^(q t); 3-5: W_4096^(q t); 6, 7: stage 2's pair for the thread's block parity -- (1, W_1024^(2v)) for an
+// even block, (W_1024^v, W_1024^(3v)) for an odd one; 8-10: W_256^(q v); 11-13: W_64^(q v); q = 1, 2, 3, v = t mod 16, block = t / 16.
 // `w` is the row W_N^j, direction-folded.  tools/model_fft_big_r4.py is the index arithmetic's model.
 int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void **dev)
 {
-    const uint32_t T = n / 32;
+    const uint32_t T = n / 32, R = sdsp_hip_log2(n) - 10; // R = 4 (N = 16384) or 2 (N = 4096); v = t mod 2^R, block = t >> R
     std::vector<float> tab((size_t)14 * T * 2);
     auto put = [&](uint32_t slot, uint32_t t, uint64_t idx) {
         idx %= n;
@@ -212,15 +212,15 @@ int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void
         tab[((size_t)slot * T + t) * 2 + 1] = (float)w[2 * idx + 1];
     };
     for (uint32_t t = 0; t < T; t++) {
-        const uint32_t v = t & 15, odd = (t >> 4) & 1;
+        const uint32_t v = t & ((1u << R) - 1), odd = (t >> R) & 1;
         for (uint32_t q = 1; q <= 3; q++) {
-            put(q - 1, t, (uint64_t)q * t);           // W_N^(q t)
-            put(2 + q, t, (uint64_t)4 * q * t);       // W_4096^(q t) = W_N^(4 q t)
-            put(7 + q, t, (uint64_t)(n / 256) * q * v); // W_256^(q v)
-            put(10 + q, t, (uint64_t)(n / 64) * q * v); // W_64^(q v)
+            put(q - 1, t, (uint64_t)q * t);        // W_N^(q t)
+            put(2 + q, t, (uint64_t)4 * q * t);    // W_(N/4)^(q t) = W_N^(4 q t)
+            put(7 + q, t, (uint64_t)64 * q * v);   // W_(2^(R+4))^(q v) = W_N^(64 q v)    (N = 16384: W_256^(q v))
+            put(10 + q, t, (uint64_t)256 * q * v); // W_(2^(R+2))^(q v) = W_N^(256 q v)   (N = 16384: W_64^(q v))
         }
-        put(6, t, odd ? (uint64_t)(n / 1024) * v : 0);                       // j < 16: q = 1 (odd block) / none
-        put(7, t, (uint64_t)(n / 1024) * (odd ? 3 : 2) * v);                 // j >= 16: q = 3 (odd) / 2 (even)
+        put(6, t, odd ? (uint64_t)16 * v : 0);             // stage 2 (G = N/16), j < 16: q = 1 (odd block) / none
+        put(7, t, (uint64_t)16 * (odd ? 3 : 2) * v);       // j >= 16: q = 3 (odd) / 2 (even)
     }
     HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -228,7 +228,7 @@ int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void
 }
 
 // N = 16384 radix-4 plans: fft_big.hip's radix-4 form is variant 0 and the fft_mix.hip kernel variant 1
-inline bool big_r4_form(uint32_t n, int radix) { return n == 16384 && radix == 4; } // table and launch of the radix-4 form
+inline bool big_r4_form(uint32_t n, int radix) { return radix == 4 && (n == 16384 || n == 4096); } // table of the radix-4 form (4096: real-input plans)
 // (N = 8192, AUTO plans: fft_big.hip's radix-2 stages measured 76.9-77.9 % against 74.1-76.2 % for the mixed-radix kernel in one
 // run once their thread twiddles were fetched ahead of the passes, so they are variant 0 there too and fft_mix.hip variant 1)
 inline bool big_is_default(uint32_t n, int radix) { return big_r4_form(n, radix) || n == 8192; }
@@ -875,7 +875,7 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
     std::vector<double> w;
     if (big_real && !p->twt_big) { // (every complex plan this kernel serves has the table already)
         make_twiddles(n, direction, w);
-        if (int rc = upload_thread_twiddles_big(w, n, &p->twt_big)) {
+        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, &p->twt_big)) {
             sdsp_hip_fft_plan_destroy(p);
             return rc;
         }

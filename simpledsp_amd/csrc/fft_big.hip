@@ -61,8 +61,8 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
 // One transform per workgroup (two / four consecutive transforms on a larger workgroup measured slower at N = 4096:
 // 69.9 % (1), 66.9 % (2), 63.2 % (4) -- the barriers span more waves).
 // Four waves per SIMD for every size (<= 128 VGPRs: 124 / 124 / 127 at N = 8192 / 16384 / 32768, no scratch).
-// R4 (N = 16384 = 4^7 only): the fourteen layers run as seven radix-4 DIF stages (fft32_r4.h) -- two stages, then half of the
-// third in pass A; its other half and two stages in pass B; two stages in pass C -- with their own thread-twiddle table
+// R4 (N = 16384 = 4^7; N = 4096 = 4^6 for real-input plans): the layers run as radix-4 DIF stages (fft32_r4.h) -- two stages, then half
+// of the third in pass A; its other half and two stages in pass B; two stages (N = 4096: one) in pass C -- with their own thread-twiddle table
 // (capi.hip: upload_thread_twiddles_big_r4); loads, exchanges and the store are the same.
 // CONV (forward plans): the fused fast convolution data <- IFFT(FFT(data) .* h) of SURVEY 8(f)-1.  The forward
 // transform leaves register i holding X[t + T * bit_reverse5(i)]; multiplied by h there (rows of h through a buffer resource,
@@ -82,7 +82,7 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
 {
     static_assert(!CONV || !REV, "the fused convolution belongs to forward plans");
     static_assert(REAL == 0 || (!CONV && (REAL == 1) == !REV), "real-input packing: split forward, merge reverse");
-    static_assert(!R4 || L == 14, "radix-4 stages: N = 16384");
+    static_assert(!R4 || L == 14 || L == 12, "radix-4 stages: N = 16384 (and N = 4096 for the real-input form)");
     constexpr int R = L - 10;
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big_smem[]; // N floats: one plane of the transform
@@ -146,10 +146,10 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
             for (int q = 0; q < 3; q++)
                 thr[q] = tab(3 + q); // W_4096^((q + 1) t)
             r4_stage<RV, 2, 1, 8, true>(y, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
-            // stage 2, first layer: register bit 0 is index bit 9, index bit 8 is the thread's: the quarter (1, 1) = odd
-            // registers of the threads t >= 256
+            // stage 2, first layer: register bit 0 is index bit L - 5, index bit L - 6 is the thread's top bit: the quarter (1, 1) =
+            // odd registers of the upper half of the threads
             layer<1>(y);
-            const bool upper = t >= 256;
+            const bool upper = t >= T / 2;
 #pragma unroll
             for (int k = 1; k < 32; k += 2) {
                 const float2 r = rot_i<RV>(y[k]);
@@ -237,9 +237,11 @@ __global__ __launch_bounds__((1 << L) / 32, 4) void sdsp_fft_big_kernel(float2 *
         }
 
         if constexpr (R4) {
-            const float2 none[3] = {};
-            r4_stage<RV, 3, 3, 4, false>(y, none); // stage 5: register bits 3, 2; constants W_16^(q (i & 3)) only
-            r4_layers<RV, 1>(y);                   // stage 6: no twiddles
+            if constexpr (R == 4) {
+                const float2 none[3] = {};
+                r4_stage<RV, 3, 3, 4, false>(y, none); // stage 5: register bits 3, 2; constants W_16^(q (i & 3)) only
+            }
+            r4_layers<RV, 1>(y); // the last stage (register bits 1, 0): no twiddles
         } else {
             fft32_dif<RV, false, 5 - R>(y, tw, 0);
         }
@@ -378,7 +380,7 @@ template <int L> int launch_dir(const fft_reg_args &a, hipStream_t s)
     if (a.real_mode == 1 || a.real_mode == 2) { // real-input packing: a.tw2 = W_2N^j
         if (!a.tw2 || (a.real_mode == 1) != !a.reverse)
             return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_big real-input packing: split forward / merge reverse, W_2N needed");
-        if constexpr (L == 14) {
+        if constexpr (L == 14 || L == 12) {
             if (a.radix == 4) // a.tw: the radix-4 table
                 return a.reverse ? launch_l<L, true, true, true, false, 2>(a, s) : launch_l<L, false, true, true, false, 1>(a, s);
         }
@@ -416,12 +418,14 @@ bool fft_big_supports(uint32_t n, int radix)
     return radix == 2 && (n == 8192 || n == 16384 || n == 32768);
 }
 
-// real-input plans (n = n_real / 2) and the fused convolution: radix-2 stages n = 2048 .. 32768, radix-4 stages n = 16384
-bool fft_big_real_supports(uint32_t n, int radix)
+// the fused convolution and real-input plans (n = n_real / 2): radix-2 stages n = 2048 .. 32768, radix-4 stages n = 16384
+bool fft_big_conv_supports(uint32_t n, int radix)
 {
     return (radix == 2 && (n == 2048 || n == 4096 || n == 8192 || n == 16384 || n == 32768)) || (radix == 4 && n == 16384);
 }
-bool fft_big_conv_supports(uint32_t n, int radix) { return fft_big_real_supports(n, radix); }
+// (N = 4096 radix 4: the radix-4 form exists for the real-input plans only -- the complex transform and its convolution have
+// the tuned kernels of fft4096.hip)
+bool fft_big_real_supports(uint32_t n, int radix) { return fft_big_conv_supports(n, radix) || (radix == 4 && n == 4096); }
 
 int launch_fft_big_f32(const fft_reg_args &a, void *stream)
 {

@@ -457,7 +457,7 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
 @pytest.mark.parametrize("n_real,radix,batch,precision", [(32, 2, 5, "f32"), (32, 4, 130, "f32"), (128, 4, 33, "f32"), (1024, 2, 7, "f32"),
                                                            (512, 2, 1027, "f32"), (512, 2, 2, "f32"), (512, 4, 1029, "f32"), (1024, 2, 130, "f32"), (2048, 2, 1030, "f32"), (4096, 2, 9, "f32"),
                                                            (2048, 4, 5, "f32"), (8192, 2, 3, "f32"), (8192, 4, 2, "f32"), (32768, 2, 2, "f32"), (32768, 2, 67, "f32"),
-                                                           (16384, 2, 1, "f32"), (16384, 2, 131, "f32"), (32768, 4, 2, "f32"), (32768, 4, 41, "f32"), (8192, 2, 300, "f32"), (65536, 2, 1, "f32"), (65536, 2, 19, "f32"),
+                                                           (16384, 2, 1, "f32"), (16384, 2, 131, "f32"), (32768, 4, 2, "f32"), (32768, 4, 41, "f32"), (8192, 4, 9, "f32"), (8192, 2, 300, "f32"), (65536, 2, 1, "f32"), (65536, 2, 19, "f32"),
                                                            (32, 2, 70, "f64"), (128, 4, 33, "f64"), (2048, 4, 5, "f64"), (16384, 2, 2, "f64")])
 def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precision):
     """SURVEY 8(f)-3.  Checker: the reference algorithm on the real signal as a complex one (what the
@@ -495,7 +495,7 @@ def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precis
     wave = not f64 and (half == 256 or (radix == 2 and half in (512, 1024)))  # where the wave kernels measured faster (capi.hip)
     # f32, radix 2, n_real / 2 = 8192 / 16384: split / merge inside the registers-resident kernel (csrc/fft_big.hip, REAL: the pairs
     # meet in LDS); variant 1 the register-pass family's, as above
-    big = not f64 and ((radix == 2 and half in (2048, 4096, 8192, 16384, 32768)) or (radix == 4 and half == 16384))
+    big = not f64 and ((radix == 2 and half in (2048, 4096, 8192, 16384, 32768)) or (radix == 4 and half in (4096, 16384)))
     assert fwd.info.kernel.decode() == ("sdsp_fft1024_wave" if wave and half == 1024 else "sdsp_fft_wave_f32" if wave else
                                         "sdsp_fft_big_kernel" if big else
                                         "sdsp_fft_reg_f64_kernel" if f64 else "sdsp_fft_reg_kernel")

@@ -10,8 +10,10 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("script", ["model_fft_big_lds.py", "model_fft_big_r4.py"])
+@pytest.mark.parametrize("script", ["model_fft_big_lds.py", "model_fft_big_r4.py 14", "model_fft_big_r4.py 14 rev", "model_fft_big_r4.py 12",
+                                    "model_fft_big_r4.py 12 rev"])
 def test_model_script_passes(script):
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / script)], capture_output=True, text=True, timeout=300)
+    name, *rest = script.split()
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / name), *rest], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "equal sw<" in r.stdout or "max rel err" in r.stdout
