@@ -366,7 +366,7 @@ template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL
 
 // PF (the kernel's last template argument): fetch a pass's thread twiddles ahead of it -- pass A's under the data loads, pass
 // B's under the first exchange -- instead of at each stage's start behind the exchange's barriers.  One-process A/B
-// (tools/lab_pf.py history in profiles/r02_fft_big_lab.md): complex N = 8192 +1.2 points, N = 16384 +2.3; N = 32768 -1.2 and the
+// (profiles/r02_fft_big_lab.md, section 7): complex N = 8192 +1.2 points, N = 16384 +2.3; N = 32768 -1.2 and the
 // real-input forms -0.4 .. -1.6 (their registers are full: the ten extra live values cost more than the round trip) -- so it is
 // on for the plain radix-2 transforms up to N = 16384 only.
 template <int L, bool REV, bool NT, bool R4 = false, bool CONV = false, int REAL = 0> int launch_l(const fft_reg_args &a, hipStream_t s)
