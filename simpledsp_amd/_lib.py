@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
@@ -34,6 +35,7 @@ class PlanInfo(C.Structure):
         ("n", C.c_uint32), ("radix", C.c_int), ("direction", C.c_int), ("precision", C.c_int),
         ("device", C.c_int), ("hbm_passes", C.c_int), ("algorithmic_bytes", C.c_uint64),
         ("workspace_bytes", C.c_uint64), ("twiddle_bytes", C.c_uint64), ("kernel", C.c_char * 64),
+        ("stage_radix", C.c_int),
     ]
 
 
@@ -67,6 +69,8 @@ SIGNATURES = {
     "sdsp_hip_fft_plan_get_twiddles": (_i, [_vp, _vp]),
     "sdsp_hip_fft_plan_set_variant": (_i, [_vp, _i]),
     "sdsp_hip_fft_plan_status": (_i, [_vp]),
+    "sdsp_hip_fft_plan_set_wait_limit": (_i, [_vp, _u64]),
+    "sdsp_hip_fft_plan_launches": (_i, [_vp, _u64, C.POINTER(_u64)]),
     "sdsp_hip_set_launch_piece_bytes": (_i, [_u64]),
     "sdsp_hip_get_launch_piece_bytes": (_i, [C.POINTER(_u64)]),
     "sdsp_hip_iir_design_lp": (_i, [_u32, _d, _d, _d, _vp, _vp, C.POINTER(_d)]),
@@ -94,6 +98,35 @@ SIGNATURES = {
 _lib = None
 
 
+class StaleLibraryError(RuntimeError):
+    """libsdsp_hip.so does not match the sources beside it"""
+
+
+def built_hash(lib) -> str:
+    """the source hash the library was built from (sdsp_hip_version() ends in "src:<hash>")"""
+    lib.sdsp_hip_version.restype = C.c_char_p
+    v = lib.sdsp_hip_version().decode()
+    return v.rsplit("src:", 1)[1] if "src:" in v else "unhashed"
+
+
+def _open(path, fresh: bool = False) -> C.CDLL:
+    if fresh:  # dlopen caches by path: load the rebuilt file through a private copy
+        import shutil
+        import tempfile
+        tmp = Path(tempfile.mkdtemp(prefix="sdsp_hip_")) / path.name
+        shutil.copy2(path, tmp)
+        path = tmp
+    return C.CDLL(str(path))
+
+
+def _bind(lib) -> C.CDLL:
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
     """Load libsdsp_hip.so (building it with hipcc first if it is not there)."""
     global _lib
@@ -108,18 +141,26 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
+    from .build import build_library, source_hash
     if not LIB_PATH.exists():
         if not build_if_missing:
             raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -m simpledsp_amd.build`")
-        from .build import build_library
         build_library()
-    lib = C.CDLL(str(LIB_PATH))
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    lib = _open(LIB_PATH)
+    # a library built from other sources than the ones beside it (an edited header whose object was not rebuilt, a .so
+    # left over from another checkout) must not be what gets tested and benched: rebuild, or refuse
+    want = source_hash()
+    if built_hash(lib) != want:
+        if not build_if_missing or os.environ.get("SDSP_HIP_NO_REBUILD") == "1":
+            raise StaleLibraryError(f"{LIB_PATH} was built from other sources (library {built_hash(lib)}, tree {want}): "
+                                    "run `python -m simpledsp_amd.build`")
+        print(f"simpledsp_amd: {LIB_PATH.name} is stale ({built_hash(lib)} != {want}), rebuilding", file=sys.stderr)
+        build_library()
+        lib = _open(LIB_PATH, fresh=True)
+        if built_hash(lib) != want:
+            raise StaleLibraryError(f"{LIB_PATH} still reports {built_hash(lib)} after a rebuild (tree {want})")
+    _lib = _bind(lib)
+    return _lib
 
 
 def check(rc: int) -> None:

@@ -5,6 +5,7 @@ simpledsp_amd/lib/ so that it travels with the source snapshot to the GPU box.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -51,25 +52,65 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm to build libsdsp_hip.so)")
 
 
+def source_hash() -> str:
+    """sha256 over everything the library is built from: csrc/*, include/**, and this file's flags"""
+    h = hashlib.sha256()
+    files = sorted(CSRC.glob("*")) + sorted((ROOT / "include").rglob("*.h")) + [Path(__file__)]
+    for f in files:
+        if f.is_file():
+            h.update(f.relative_to(ROOT).as_posix().encode())
+            h.update(b"\0")
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def _dep_files(dfile: Path):
+    """prerequisites listed in a compiler-written Makefile fragment (-MMD -MF), or None when it is missing"""
+    if not dfile.exists():
+        return None
+    text = dfile.read_text().replace("\\\n", " ")
+    deps = []
+    for line in text.splitlines():
+        if ":" in line:
+            deps += line.split(":", 1)[1].split()
+    return [Path(d) for d in deps]
+
+
 def _stale(target: Path, deps) -> bool:
     if not target.exists():
         return True
     t = target.stat().st_mtime
-    return any(Path(d).stat().st_mtime > t for d in deps)
+    return any((not Path(d).exists()) or Path(d).stat().st_mtime > t for d in deps)
+
+
+def object_stale(obj: Path, src: Path) -> bool:
+    """an object is rebuilt when the compiler's own dependency list for it (every header it included, transitively) has a
+    newer file, or when that list does not exist yet; build.py itself (the flags) counts as a prerequisite"""
+    deps = _dep_files(obj.with_suffix(".d"))
+    if deps is None:
+        return True
+    return _stale(obj, [src, Path(__file__), *deps])
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    headers = [CSRC / "sdsp_hip_internal.h", CSRC / "fft_passes.h", CSRC / "fft32.h", CSRC / "fft1m_kernels.h", CSRC / "fft4096_kernels.h", ROOT / "include" / "sdsp_hip.h", Path(__file__)]
+    digest = source_hash()
+    stamp = OBJ_DIR / "source_hash.txt"
     jobs = []
     objs = []
     for src, extra in SOURCES.items():
         obj = OBJ_DIR / (src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [CSRC / src, *headers]):
-            jobs.append([cc, *COMMON, *extra, "-c", str(CSRC / src), "-o", str(obj)])
+        flags = list(extra)
+        stale = force or object_stale(obj, CSRC / src)
+        if src == "host_math.cpp":  # carries the hash: rebuilt whenever any source changed
+            flags.append(f'-DSDSP_HIP_SOURCE_HASH="{digest}"')
+            stale = stale or not stamp.exists() or stamp.read_text().strip() != digest
+        if stale:
+            # -MMD -MF: hipcc compiles host and device in one go; the host pass writes the dependency file
+            jobs.append([cc, *COMMON, *flags, "-MMD", "-MF", str(obj.with_suffix(".d")), "-c", str(CSRC / src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
@@ -84,6 +125,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB_PATH, objs):
         run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB_PATH), "-lpthread"])
+    stamp.write_text(digest + "\n")
     return LIB_PATH
 
 

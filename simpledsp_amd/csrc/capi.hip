@@ -288,6 +288,7 @@ struct sdsp_hip_fft_plan {
     uint64_t host_stage_bytes = 0;
     void *sync = nullptr;          // N = 2^20: the persistent kernel's ticket / arrival counters
     uint64_t sync_count = 0;       // ... transforms one launch of it covers
+    uint64_t wait_limit = 200000000ull; // ... and what a hand-off poll may take (100 MHz ticks: 2 s) before the launch gives up
     sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
     sdsp_hip_fft_plan *mid_rows = nullptr; // N = 2^16 .. 2^19 f32: plan of the 16 row transforms (fft_mid.hip)
     void *tw1024 = nullptr;                // ... and W_1024^j, the coarse factor of its inter-pass twiddle
@@ -335,37 +336,136 @@ int ensure_workspace(sdsp_hip_fft_plan *p)
     return SDSP_HIP_OK;
 }
 
+// chunk sizes of the multi-pass schedules (shared by exec and the launch count)
+uint64_t fft1m_chunk(const sdsp_hip_fft_plan *p) { return std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch)); }
+uint64_t fft2p_chunk(const sdsp_hip_fft_plan *p) { return std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 25) / p->n)); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The ONE dispatch table: which kernel serves (plan, variant).  sdsp_hip_fft_exec, sdsp_hip_fft_plan_get_info and
+// sdsp_hip_fft_plan_launches all go through select_kernel(), so what the plan reports is what runs, by construction.
+enum fft_kernel_id {
+    K_NOOP = 0,
+    K_FFT4096_R4,    // fft4096.hip: the headline kernel (cfg 2 / 5)
+    K_FFT4096_R2,    // fft4096.hip: its radix-2 sibling
+    K_MIX,           // fft_mix.hip: one leading radix-2 / radix-4 stage + the N = 4096 radix-4 machinery
+    K_BIG,           // fft_big.hip: transform in registers, N = 8192 .. 32768
+    K_BIG_REAL,      // fft_big.hip, REAL form (real-input plans, n = n_real / 2 = 2048 .. 32768)
+    K_BIG64,         // fft_big64.hip: the same design in double, N = 4096 .. 16384
+    K_REG64,         // fft_reg64.hip: register-pass family in double
+    K_WAVE64,        // fft_wave.hip: N = 1024 in double, one transform per two waves
+    K_WAVE1024,      // fft_wave.hip: N = 1024 f32, one transform per wave
+    K_WAVE2,         // fft_wave.hip: N = 256 / 512 / 2048 f32
+    K_REG32,         // fft_reg.hip: register-pass family, f32
+    K_TILE,          // fft_tile.hip: coverage kernel, one pass
+    K_FFT1M_CHUNKED, // fft1m.hip: two launches per chunk of <= 32 transforms
+    K_FFT1M_FUSED,   // fft1m.hip: one persistent launch (cfg 3)
+    K_2PASS,         // fft_2pass.hip: N = N1 x N2, two passes
+    K_MID,           // fft_mid.hip: 16-point column step + row plan + untwist
+    K_FOUR_STEP,     // fft_tile.hip twice: the general four-step
+    K_UNSUPPORTED,   // no kernel serves this (plan, variant)
+};
+
+struct fft_kernel_sel {
+    fft_kernel_id id;
+    const char *name;  // as rocprofv3 prints the dominant kernel(s)
+    int hbm_passes;    // passes over HBM of one transform
+    int stage_radix;   // butterflies that run: 2, 4, or SDSP_HIP_STAGES_2_THEN_4
+    bool workspace;    // needs the plan-owned workspace
+    bool pieces;       // one launch per batch, issued in launch pieces (sdsp_hip_set_launch_piece_bytes)
+};
+
+fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
+{
+    const bool f32 = p->precision == SDSP_HIP_F32;
+    // launch pieces: kernels with many short workgroups (N <= 8192); see fft_exec_pieces
+    const bool pc = (p->path == PATH_FFT4096 || p->path == PATH_REG || p->path == PATH_TILE) && p->n <= 8192;
+    if (p->path == PATH_NOOP)
+        return { K_NOOP, "none", 0, p->radix, false, false };
+    if (p->path == PATH_FFT4096 && variant < fft4096_num_variants())
+        return { K_FFT4096_R4, "sdsp_fft4096_r4_f32", 1, 4, false, pc };
+    if (p->path == PATH_REG && f32 && variant == 0 && p->n == 4096 && p->radix == 2 && !p->real_mode)
+        return { K_FFT4096_R2, "sdsp_fft4096_r2_f32", 1, 2, false, pc };
+    // N = 8192 / 16384 f32, either stage type: one leading radix-2 / radix-4 stage + the tuned N = 4096 radix-4 machinery
+    const bool mix_size = p->path == PATH_REG && f32 && !p->real_mode && p->tw_lead;
+    const int mix_variant = big_is_default(p->n, p->radix) ? 1 : 0;
+    if (mix_size && variant == mix_variant)
+        return { K_MIX, "sdsp_fft_mix_f32", 1, p->n == 8192 ? SDSP_HIP_STAGES_2_THEN_4 : 4, false, pc };
+    // N = 32768 (variant 0) and N = 8192 / 16384 (variant 0 or 1, see big_is_default), f32: registers-resident kernel
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && f32 && variant == (mix_size ? 1 - mix_variant : 0) && !p->real_mode &&
+        fft_big_supports(p->n, p->radix))
+        return { K_BIG, "sdsp_fft_big_kernel", 1, big_r4_form(p->n, p->radix) ? 4 : 2, false, pc };
+    // real-input plans of n_real = 4096 .. 65536: split / merge inside the registers-resident kernel; variants 1 / 2 keep
+    // the register-pass family's MODE 1 / 2
+    if (p->path == PATH_REG && f32 && variant == 0 && p->real_mode && p->twt_big && fft_big_real_supports(p->n, p->radix))
+        return { K_BIG_REAL, "sdsp_fft_big_kernel", 1, big_r4_form(p->n, p->radix) ? 4 : 2, false, pc };
+    if (p->path == PATH_REG && !f32) {
+        const bool wave64 = !p->real_mode && fft_wave_supports(p->n, p->radix);
+        if (variant == 1 && wave64) // N = 1024 alternate: same bits; measured 71.4-72.1 % against 71.7-72.6 %: no gain in double
+            return { K_WAVE64, "sdsp_fft1024_wave", 1, p->radix, false, pc };
+        if (variant == 0)
+            return { K_REG64, "sdsp_fft_reg_f64_kernel", 1, p->radix, false, pc };
+    }
+    if (p->path == PATH_REG && f32 && variant < 3) {
+        // one-wave kernels (fft_wave.hip), where they measured faster than the register-pass family.  Complex transform:
+        // N = 1024 (either stage type), N = 256 / 2048 radix 2 (N = 512: 72.1-72.8 % against 74.2-74.8 % there).  Real-input
+        // plans (split / merge by ds_bpermute): n_real = 512 / 1024 / 2048 radix 2: 71.9 / 70.5 / 67.3 % against 70.6 / 66.5 /
+        // 66.2 % (radix 4 at 2048: 65.5 / 65.6; n_real = 4096: 59.8 against 64.5 %, 174 VGPRs -- both stay with the family)
+        if (variant == 0 && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
+            return { K_WAVE1024, "sdsp_fft1024_wave", 1, p->radix, false, pc };
+        if (variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
+            return { K_WAVE2, "sdsp_fft_wave_f32", 1, p->radix, false, pc };
+        return { K_REG32, "sdsp_fft_reg_kernel", 1, p->radix, false, pc };
+    }
+    if (p->real_mode)
+        return { K_UNSUPPORTED, "none", 0, p->radix, false, false };
+    if (p->path == PATH_TILE || p->path == PATH_FFT4096 || p->path == PATH_REG)
+        return { K_TILE, "sdsp_fft_tile_kernel", 1, p->radix, false, pc };
+    // ---- everything below is multi-pass and uses the plan's workspace
+    if (p->path == PATH_FFT1M && variant < 2) {
+        if (variant == 1 || p->ws_batch < kFft1mQueues * kFft1mRing)
+            return { K_FFT1M_CHUNKED, "sdsp_fft1m_cols+sdsp_fft1m_rows", 2, 2, true, false };
+        return { K_FFT1M_FUSED, "sdsp_fft1m_fused", 2, 2, true, false };
+    }
+    const bool two_pass_size = f32 && fft_2pass_supports(p->n);
+    if (p->path == PATH_FOUR_STEP && variant == 0 && two_pass_size)
+        return { K_2PASS, "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2, true, false };
+    // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel (or, nested, on another plan)
+    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == (two_pass_size ? 1 : 0)) {
+        const fft_kernel_sel rows = select_kernel(p->mid_rows, p->mid_rows->variant);
+        // the column step is four radix-2 stages (fft_mid.hip), whatever runs in the rows
+        return { K_MID, "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 2 + rows.hbm_passes,
+                 rows.stage_radix == 2 ? 2 : SDSP_HIP_STAGES_2_THEN_4, true, false };
+    }
+    return { K_FOUR_STEP, "sdsp_fft_tile_kernel", 2, p->radix, true, false };
+}
+
 // `variant`: the kernel variant to run (normally the plan's; the convolution path overrides it without touching the plan)
 int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream, int variant)
 {
     if (batch == 0 || p->path == PATH_NOOP)
         return SDSP_HIP_OK;
     const bool rev = p->direction == SDSP_HIP_REVERSE;
+    const fft_kernel_sel sel = select_kernel(p, variant);
+    if (sel.workspace)
+        if (int rc = ensure_workspace(p))
+            return rc;
 
-    if (p->path == PATH_FFT4096 && variant < fft4096_num_variants()) {
+    switch (sel.id) {
+    case K_NOOP:
+        return SDSP_HIP_OK;
+    case K_UNSUPPORTED:
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans have no alternative kernel variant");
+    case K_FFT4096_R4:
+    case K_FFT4096_R2: {
         fft4096_args a;
         a.data = data;
         a.tw = p->twt;
         a.batch = batch;
         a.scale = 1.0f / 4096.0f;
         a.reverse = rev;
-        return launch_fft4096_r4_f32(a, variant, stream);
+        return sel.id == K_FFT4096_R4 ? launch_fft4096_r4_f32(a, variant, stream) : launch_fft4096_r2_f32(a, stream);
     }
-
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->n == 4096 && p->radix == 2 && !p->real_mode) {
-        fft4096_args a;
-        a.data = data;
-        a.tw = p->twt;
-        a.batch = batch;
-        a.scale = 1.0f / 4096.0f;
-        a.reverse = rev;
-        return launch_fft4096_r2_f32(a, stream);
-    }
-
-    // N = 8192 / 16384 f32, either stage type: one leading radix-2 / radix-4 stage + the tuned N = 4096 radix-4 machinery
-    const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
-    const int mix_variant = big_is_default(p->n, p->radix) ? 1 : 0;
-    if (mix_size && variant == mix_variant) {
+    case K_MIX: {
         fft_mix_args a;
         a.data = data;
         a.tw = p->twt_mix;
@@ -376,11 +476,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.reverse = rev;
         return launch_fft_mix_f32(a, stream);
     }
-
-    // N = 32768 (variant 0) and N = 8192 / 16384 (variant 1), f32: radix-2 stages, registers-resident single-pass kernel
-    // (fft_big.hip)
-    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 && variant == (mix_size ? 1 - mix_variant : 0) &&
-        !p->real_mode && fft_big_supports(p->n, p->radix)) {
+    case K_BIG:
+    case K_BIG_REAL: {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_big;
@@ -390,29 +487,14 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
         a.nontemporal = 1;
+        if (sel.id == K_BIG_REAL) {
+            a.real_mode = p->real_mode;
+            a.tw2 = p->tw2;
+        }
         return launch_fft_big_f32(a, stream);
     }
-
-    // real-input plans of n_real = 8192 .. 65536 (N = 4096 .. 32768 complex), radix-2 stages: split / merge inside the
-    // registers-resident kernel (fft_big.hip, REAL); variants 1 / 2 keep the register-pass family's MODE 1 / 2
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant == 0 && p->real_mode && p->twt_big &&
-        fft_big_real_supports(p->n, p->radix)) {
-        fft_reg_args a;
-        a.data = data;
-        a.tw = p->twt_big;
-        a.n = p->n;
-        a.radix = p->radix;
-        a.batch = batch;
-        a.scale = (float)(1.0 / p->n);
-        a.reverse = rev;
-        a.nontemporal = 1;
-        a.real_mode = p->real_mode;
-        a.tw2 = p->tw2;
-        return launch_fft_big_f32(a, stream);
-    }
-
-    const bool wave64 = p->path == PATH_REG && p->precision == SDSP_HIP_F64 && !p->real_mode && fft_wave_supports(p->n, p->radix);
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && (variant == 0 || (variant == 1 && wave64))) {
+    case K_REG64:
+    case K_WAVE64: {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;
@@ -425,40 +507,27 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.nontemporal = 1;
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
-        if (wave64 && variant == 1) // N = 1024 alternate: one transform per wave (same bits; measured 71.4-72.1 % against
-            return launch_fft_wave_f64(a, stream); // 71.7-72.6 % for the register-pass kernel: no gain in double)
-        return launch_fft_reg_f64(a, stream);
+        return sel.id == K_WAVE64 ? launch_fft_wave_f64(a, stream) : launch_fft_reg_f64(a, stream);
     }
-
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && variant < 3) {
+    case K_WAVE1024:
+    case K_WAVE2:
+    case K_REG32: {
         fft_reg_args a;
         a.data = data;
-        a.tw = p->twt_reg;
+        a.tw = sel.id == K_WAVE2 ? p->twt_wave : p->twt_reg;
         a.n = p->n;
         a.radix = p->radix;
         a.batch = batch;
         a.scale = (float)(1.0 / p->n);
         a.reverse = rev;
-        a.nontemporal = variant != 1 || mix_size; // 1: default cache policy (N < 8192)
+        a.nontemporal = variant != 1 || (p->tw_lead && !p->real_mode); // variant 1: default cache policy (N < 8192)
         a.real_mode = p->real_mode;
         a.tw2 = p->tw2;
-        // one-wave kernels (fft_wave.hip), where they measured faster than this family.  Complex transform: N = 1024 (either
-        // stage type), N = 256 / 2048 radix 2 (N = 512: 72.1-72.8 % against 74.2-74.8 % here).  Real-input plans (split /
-        // merge by ds_bpermute): n_real = 512 / 1024 / 2048 radix 2: 71.9 / 70.5 / 67.3 % against 70.6 / 66.5 / 66.2 %
-        // (radix 4 at 2048: 65.5 / 65.6; n_real = 4096: 59.8 against 64.5 %, 174 VGPRs -- both stay here)
-        if (variant == 0 && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
+        if (sel.id == K_WAVE1024)
             return launch_fft_wave_f32(a, stream);
-        if (variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512)) {
-            a.tw = p->twt_wave;
-            return launch_fft_wave2_f32(a, stream);
-        }
-        return launch_fft_reg_f32(a, stream);
+        return sel.id == K_WAVE2 ? launch_fft_wave2_f32(a, stream) : launch_fft_reg_f32(a, stream);
     }
-
-    if (p->real_mode)
-        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans have no alternative kernel variant");
-
-    if (p->path == PATH_TILE || p->path == PATH_FFT4096 || p->path == PATH_REG) {
+    case K_TILE: {
         fft_tile_args a{};
         a.in = data;
         a.out = data;
@@ -482,16 +551,16 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         const uint64_t tiles = (batch + p->cols - 1) / p->cols;
         return launch_fft_tile(p->precision, p->radix, a, tiles, stream);
     }
+    default:
+        break; // the multi-pass kernels follow
+    }
 
-    if (int rc = ensure_workspace(p)) // every path below is multi-pass
-        return rc;
-
-    if (p->path == PATH_FFT1M && variant < 2) {
+    if (sel.id == K_FFT1M_CHUNKED || sel.id == K_FFT1M_FUSED) {
         const uint64_t N = 1ull << 20;
         const float scale = (float)(1.0 / (double)N);
-        if (variant == 1 || p->ws_batch < kFft1mQueues * kFft1mRing) {
+        if (sel.id == K_FFT1M_CHUNKED) {
             // two launches per chunk of <= 32 transforms (round 1's schedule; also what plans with a small workspace run)
-            const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch));
+            const uint64_t chunk = fft1m_chunk(p);
             for (uint64_t done = 0; done < batch; done += chunk) {
                 fft1m_args a;
                 a.data = reinterpret_cast<char *>(data) + done * N * 8;
@@ -516,6 +585,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.workspace = p->workspace;
             a.tw_1024 = p->tw1;
             a.sync = p->sync;
+            a.sticky = reinterpret_cast<char *>(p->sync) + fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues);
+            a.spin_limit = p->wait_limit;
             a.count = std::min<uint64_t>(p->sync_count, batch - done);
             // a ring of 4 with pass 2 two steps behind measured 42.0-42.2 %, 3 / one step 41.4-41.6 % (profiles/r02_fft1m_lab.md)
             a.ring = p->ws_batch >= 4 * kFft1mQueues ? 4 : (uint32_t)kFft1mRing;
@@ -530,8 +601,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     }
 
     // N = 2^16 .. 2^19, f32: two passes over HBM (fft_2pass.hip), in chunks whose intermediate is at most 256 MiB
-    if (p->path == PATH_FOUR_STEP && p->precision == SDSP_HIP_F32 && variant == 0 && fft_2pass_supports(p->n)) {
-        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 25) / p->n));
+    if (sel.id == K_2PASS) {
+        const uint64_t chunk = fft2p_chunk(p);
         for (uint64_t done = 0; done < batch; done += chunk) {
             fft_2pass_args a;
             a.data = reinterpret_cast<char *>(data) + done * p->n * 8;
@@ -549,8 +620,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
 
     // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel: f32 N = 2^21 .. 2^23, f64
     // N = 2^14 .. 2^21, and variant 1 of the f32 sizes above
-    const bool two_pass_size = p->precision == SDSP_HIP_F32 && fft_2pass_supports(p->n);
-    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == (two_pass_size ? 1 : 0)) {
+    if (sel.id == K_MID) {
         const uint32_t n2 = p->n / 16;
         uint64_t done = 0;
         while (done < batch) {
@@ -632,16 +702,22 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
 }
 
 // single-launch paths in pieces (sdsp_hip_set_launch_piece_bytes); the multi-pass paths chunk by their workspace already
+// N <= 8192: kernels with many short workgroups, where pieces measured +1 .. +3 points (N = 64: 66.6 -> 69.8 %, 1024:
+// 68.7 -> 71.4 %, 4096: 72.1 -> 76.3 %, 8192: 75.4 -> 76.4 %, 4 GiB buffers).  The N = 16384 / 32768 kernels keep one
+// or two transforms per CU for tens of microseconds: 62.9 -> 61.3 % and 44.9 -> 43.3 % in pieces, so they stay whole.
+uint64_t fft_piece(const sdsp_hip_fft_plan *p, const fft_kernel_sel &sel, uint64_t batch)
+{
+    if (!sel.pieces)
+        return batch;
+    const uint64_t row_bytes = (uint64_t)p->n * esize(p->precision); // real-input plans: n = n_real / 2 complex elements
+    return piece_units(batch, row_bytes, p->n < 16 ? 4096 : 256);    // a multiple of what one workgroup owns
+}
+
 int fft_exec_pieces(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream, int variant)
 {
-    // N <= 8192: kernels with many short workgroups, where pieces measured +1 .. +3 points (N = 64: 66.6 -> 69.8 %, 1024:
-    // 68.7 -> 71.4 %, 4096: 72.1 -> 76.3 %, 8192: 75.4 -> 76.4 %, 4 GiB buffers).  The N = 16384 / 32768 kernels keep one
-    // or two transforms per CU for tens of microseconds: 62.9 -> 61.3 % and 44.9 -> 43.3 % in pieces, so they stay whole.
-    const bool single = (p->path == PATH_FFT4096 || p->path == PATH_REG || p->path == PATH_TILE) && p->n <= 8192;
-    if (!single)
-        return fft_exec_device(p, data, batch, stream, variant);
-    const uint64_t row_bytes = (uint64_t)p->n * esize(p->precision); // real-input plans: n = n_real / 2 complex elements
-    const uint64_t piece = piece_units(batch, row_bytes, p->n < 16 ? 4096 : 256); // a multiple of what one workgroup owns
+    const fft_kernel_sel sel = select_kernel(p, variant);
+    const uint64_t row_bytes = (uint64_t)p->n * esize(p->precision);
+    const uint64_t piece = fft_piece(p, sel, batch);
     for (uint64_t done = 0; done < batch; done += piece) {
         const uint64_t nb = std::min(piece, batch - done);
         if (int rc = fft_exec_device(p, static_cast<char *>(data) + done * row_bytes, nb, stream, variant))
@@ -649,6 +725,48 @@ int fft_exec_pieces(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
     }
     return SDSP_HIP_OK;
 }
+
+// kernel launches one sdsp_hip_fft_exec(plan, data, batch) issues with kernel variant `variant` (memsets not counted)
+uint64_t fft_launch_count(const sdsp_hip_fft_plan *p, uint64_t batch, int variant, bool in_pieces = true)
+{
+    if (batch == 0)
+        return 0;
+    const fft_kernel_sel sel = select_kernel(p, variant);
+    auto ceil_div = [](uint64_t a, uint64_t b) { return (a + b - 1) / b; };
+    switch (sel.id) {
+    case K_NOOP:
+    case K_UNSUPPORTED: return 0;
+    case K_FFT1M_CHUNKED: return 2 * ceil_div(batch, fft1m_chunk(p));
+    case K_FFT1M_FUSED: return ceil_div(batch, p->sync_count);
+    case K_2PASS: return 2 * ceil_div(batch, fft2p_chunk(p));
+    case K_FOUR_STEP: return 2 * ceil_div(batch, p->ws_batch);
+    case K_MID: {
+        uint64_t n = 0;
+        for (uint64_t done = 0; done < batch; done += p->ws_batch)
+            n += 2 + fft_launch_count(p->mid_rows, std::min<uint64_t>(p->ws_batch, batch - done) * 16, p->mid_rows->variant, false);
+        return n;
+    }
+    default: return in_pieces ? ceil_div(batch, fft_piece(p, sel, batch)) : 1;
+    }
+}
+// the persistent N = 2^20 kernel's sticky abort word: set by any launch whose bounded hand-off wait gave up, cleared by
+// sdsp_hip_fft_exec at the start of a call (the per-launch abort flag beside the tickets is re-zeroed for every launch)
+void *fft1m_sticky(const sdsp_hip_fft_plan *p)
+{
+    return reinterpret_cast<char *>(p->sync) + fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues);
+}
+
+int fft1m_check_sticky(sdsp_hip_fft_plan *p)
+{
+    if (p->path != PATH_FFT1M || !p->sync)
+        return SDSP_HIP_OK;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpy(&flag, fft1m_sticky(p), sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag)
+        return fail(SDSP_HIP_ERR_HIP, "an N = 2^20 launch gave up on a bounded wait between its two passes: the output of the last call is invalid");
+    return SDSP_HIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -821,9 +939,11 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
-            hipError_t e = hipMalloc(&p->sync, fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues));
-            if (e == hipSuccess) // the abort word must read 0 before the first persistent launch (sdsp_hip_fft_plan_status)
-                e = hipMemset(p->sync, 0, fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues));
+            // + one line behind the per-launch block for the sticky abort word (never touched by the per-launch memset)
+            const size_t sync_bytes = fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues) + 64;
+            hipError_t e = hipMalloc(&p->sync, sync_bytes);
+            if (e == hipSuccess) // the abort words must read 0 before the first persistent launch (sdsp_hip_fft_plan_status)
+                e = hipMemset(p->sync, 0, sync_bytes);
             if (e != hipSuccess)
                 rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft1m counters hipMalloc: ") + hipGetErrorString(e));
         }
@@ -841,6 +961,10 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
             rc = upload_twiddles(w, precision, &p->tw1024);
         }
     }
+    // plans whose DEFAULT kernel is multi-pass own their workspace from here on (no allocation on the launch path: stream
+    // capture works, out-of-memory is a create-time error); single-pass defaults with multi-pass alternates stay lazy
+    if (!rc && select_kernel(p, 0).workspace)
+        rc = ensure_workspace(p);
     if (rc) {
         sdsp_hip_fft_plan_destroy(p);
         return rc;
@@ -938,6 +1062,8 @@ int sdsp_hip_fft_exec(sdsp_hip_fft_plan *p, void *data, uint64_t batch, void *st
         return fail(SDSP_HIP_ERR_INVALID_ARG, "data must be aligned to one complex element");
     if (int rc = use_device(p->device))
         return rc;
+    if (p->path == PATH_FFT1M && p->sync) // this call's launches report into a clean sticky abort word
+        HIP_TRY(hipMemsetAsync(fft1m_sticky(p), 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)));
     return fft_exec_pieces(p, data, batch, reinterpret_cast<hipStream_t>(stream), p->variant);
 }
 
@@ -962,10 +1088,12 @@ int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *p, void *host_data, uint64_t batch
         p->host_stage_bytes = bytes;
     }
     HIP_TRY(hipMemcpy(p->host_stage, host_data, bytes, hipMemcpyHostToDevice));
+    if (p->path == PATH_FFT1M && p->sync)
+        HIP_TRY(hipMemsetAsync(fft1m_sticky(p), 0, sizeof(unsigned), nullptr));
     if (int rc = fft_exec_device(p, p->host_stage, batch, nullptr, p->variant))
         return rc;
     HIP_TRY(hipMemcpy(host_data, p->host_stage, bytes, hipMemcpyDeviceToHost));
-    return SDSP_HIP_OK;
+    return fft1m_check_sticky(p); // synchronous path: a launch that gave up is reported here, not only by _plan_status
 }
 
 int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void *host_data, uint64_t batch)
@@ -1113,43 +1241,13 @@ int sdsp_hip_fft_plan_get_info(const sdsp_hip_fft_plan *p, sdsp_hip_fft_plan_inf
     info->direction = p->direction;
     info->precision = p->precision;
     info->device = p->device;
-    const bool mix_size = p->path == PATH_REG && p->precision == SDSP_HIP_F32 && !p->real_mode && p->tw_lead;
-    const int mix_variant = big_is_default(p->n, p->radix) ? 1 : 0;
-    const bool big = (p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F32 &&
-                     p->variant == (mix_size ? 1 - mix_variant : 0) && !p->real_mode && fft_big_supports(p->n, p->radix);
-    const bool two_pass = p->path == PATH_FOUR_STEP && p->precision == SDSP_HIP_F32 && fft_2pass_supports(p->n);
-    const bool mid = p->path == PATH_FOUR_STEP && p->mid_rows && p->variant == (two_pass ? 1 : 0);
-    info->hbm_passes = ((p->path == PATH_FOUR_STEP && !big) || p->path == PATH_FFT1M) ? 2 : 1;
-    if (mid) { // column step + the rows' own passes + untwist
-        sdsp_hip_fft_plan_info rows;
-        sdsp_hip_fft_plan_get_info(p->mid_rows, &rows);
-        info->hbm_passes = 2 + rows.hbm_passes;
-    }
+    const fft_kernel_sel sel = select_kernel(p, p->variant); // the same table sdsp_hip_fft_exec dispatches on
+    info->hbm_passes = sel.hbm_passes;
+    info->stage_radix = sel.stage_radix;
     info->algorithmic_bytes = 2ull * p->n * esize(p->precision); // real plans: n complex = n_real floats, same bytes
     info->workspace_bytes = p->workspace_bytes;
     info->twiddle_bytes = p->twiddle_bytes;
-    const char *name = "sdsp_fft_tile_kernel";
-    if (p->path == PATH_FFT4096 && p->variant < fft4096_num_variants())
-        name = "sdsp_fft4096_r4_f32";
-    if (p->path == PATH_FFT1M && p->variant < 2)
-        name = (p->variant == 1 || p->ws_batch < kFft1mQueues * kFft1mRing) ? "sdsp_fft1m_cols+sdsp_fft1m_rows" : "sdsp_fft1m_fused";
-    if (p->path == PATH_REG && p->variant < 3)
-        name = p->precision == SDSP_HIP_F64 ? (p->variant == 0 ? "sdsp_fft_reg_f64_kernel" : "sdsp_fft_tile_kernel") :
-               p->real_mode               ? "sdsp_fft_reg_kernel" : (p->n == 4096 && p->radix == 2 && p->variant == 0) ? "sdsp_fft4096_r2_f32" : "sdsp_fft_reg_kernel";
-    if (p->path == PATH_REG && p->variant == (p->precision == SDSP_HIP_F64 ? 1 : 0) &&
-        (!p->real_mode || (p->precision == SDSP_HIP_F32 && p->radix == 2)) && fft_wave_supports(p->n, p->radix))
-        name = "sdsp_fft1024_wave";
-    if (p->path == PATH_REG && p->variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
-        name = "sdsp_fft_wave_f32";
-    if (big || (p->path == PATH_REG && p->precision == SDSP_HIP_F32 && p->variant == 0 && p->real_mode && p->twt_big &&
-                fft_big_real_supports(p->n, p->radix)))
-        name = "sdsp_fft_big_kernel";
-    if (mix_size && p->variant == mix_variant)
-        name = "sdsp_fft_mix_f32";
-    if (mid)
-        name = "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16";
-    if (two_pass && p->variant == 0)
-        name = "sdsp_fft2p_cols+sdsp_fft2p_rows";
+    const char *name = sel.name;
     std::strncpy(info->kernel, name, sizeof(info->kernel) - 1);
     return SDSP_HIP_OK;
 }
@@ -1161,12 +1259,22 @@ int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *p)
     if (int rc = use_device(p->device))
         return rc;
     HIP_TRY(hipDeviceSynchronize());
-    if (p->path == PATH_FFT1M && p->sync) { // the persistent kernel's abort word (zeroed in front of every launch)
-        unsigned flag = 0;
-        HIP_TRY(hipMemcpy(&flag, reinterpret_cast<unsigned *>(p->sync) + 32 * kFft1mQueues, sizeof(flag), hipMemcpyDeviceToHost));
-        if (flag)
-            return fail(SDSP_HIP_ERR_HIP, "the last N = 2^20 launch gave up on a bounded wait between its two passes: its output is invalid");
-    }
+    return fft1m_check_sticky(p);
+}
+
+int sdsp_hip_fft_plan_set_wait_limit(sdsp_hip_fft_plan *p, uint64_t ticks)
+{
+    if (!p)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
+    p->wait_limit = ticks;
+    return SDSP_HIP_OK;
+}
+
+int sdsp_hip_fft_plan_launches(const sdsp_hip_fft_plan *p, uint64_t batch, uint64_t *launches)
+{
+    if (!p || !launches)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    *launches = fft_launch_count(p, batch, p->variant);
     return SDSP_HIP_OK;
 }
 

@@ -57,16 +57,20 @@ int resident_grid()
 {
     // two 512-thread workgroups per CU (76 KiB of LDS, <= 128 VGPRs); a larger grid would be correct too (tickets are
     // drawn by running workgroups only), a smaller one leaves CUs idle
-    static std::atomic<int> cached{ 0 };
-    int g = cached.load();
+    // per device: a node may mix parts with different CU counts, and a plan runs on its own device
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return 512;
+    std::atomic<int> &slot = cached[dev & 63];
+    int g = slot.load();
     if (g)
         return g;
-    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
         return 512;
     g = 2 * prop.multiProcessorCount;
-    cached.store(g);
+    slot.store(g);
     return g;
 }
 
@@ -88,7 +92,8 @@ template <bool REV, int LAYOUT> int launch_fused_t(const fft1m_fused_args &a, hi
     k.flags = 0;
     k.sleep = 0;
     k.scale = a.scale;
-    k.spin_limit = 200000000ull; // 2 s at 100 MHz: far beyond any real wait; a lost hand-off aborts instead of hanging
+    k.sticky = reinterpret_cast<unsigned *>(a.sticky);
+    k.spin_limit = a.spin_limit; // default 2 s at 100 MHz: far beyond any real wait; a lost hand-off aborts instead of hanging
     const uint32_t grid = (uint32_t)resident_grid();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, s, k);
     hipError_t e = hipGetLastError();

@@ -354,6 +354,7 @@ struct fused_args {
     float2 *ws;         // queues x ring x 2^20
     const float2 *tw_1024;
     unsigned *sync;
+    unsigned *sticky;   // nullable: set to 1 by a launch that gives up; the host clears it once per API call, not per launch
     uint32_t count, ring, lag, queues;
     uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence, 4 = queue = XCD id
     uint32_t sleep;     // s_sleep argument of the polls is fixed; this many extra sleeps per poll iteration
@@ -365,8 +366,8 @@ __host__ __device__ constexpr size_t fused_sync_words(uint32_t count, uint32_t q
 __device__ __forceinline__ unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ONE lane waits until *word >= target (or the launch is aborted); returns false when it gave up
-__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned long long limit,
-                                         uint32_t extra_sleep)
+__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned *sticky,
+                                         unsigned long long limit, uint32_t extra_sleep)
 {
     if (ld_relaxed(word) >= target)
         return true;
@@ -382,6 +383,8 @@ __device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsign
                 return false;
             if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sticky)
+                    __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
             wait_word = done + 32 * (xf - a.ring * a.queues) + 16; // the ring slot's previous tenant has been read
         if (wait_word) {
             if (threadIdx.x == 0) {
-                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.spin_limit, a.sleep);
+                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.sticky, a.spin_limit, a.sleep);
                 if (!(a.flags & 2u)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

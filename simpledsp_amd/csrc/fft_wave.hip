@@ -34,6 +34,17 @@
 
 namespace sdsp_hip
 {
+// Lanes of ONE wave exchange data through LDS with no workgroup barrier: the hardware serves a wave's LDS instructions in
+// order, so a ds_read issued after a ds_write sees it.  What still has to be said is the compiler's side of it: the
+// writes of other lanes must stay in front of this lane's reads (and the reads in front of the next exchange's writes).
+// Wavefront-scope fences + the wave barrier state that dependency; they emit no instruction.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 namespace
 {
 typedef float v2f_t __attribute__((ext_vector_type(2)));
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
     run_pass(std::integral_constant<int, 0>{}, rev_tag);
 
     // ---- exchange A -> B.  A: p = t + 64 k, p >> SH = (t >> SH) | (k << (6 - SH))
+    wave_lds_sync(); // (a second transform of the fused convolution: the first one's last reads come first)
     {
         uint32_t ta = t ^ xterm_dev<SH>(t >> SH);
         asm volatile("" : "+v"(ta)); // one v_xor per access instead of sixteen live addresses
@@ -188,6 +200,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
         for (int k = 0; k < 16; k++)
             lds[64 * k + (ta ^ xterm<SH>((uint32_t)k << (6 - SH)))] = x[k];
     }
+    wave_lds_sync();
     // B: p = 64 b + v + 4 j, p >> SH = (b << (6 - SH)) | (j >> (SH - 2))
     uint32_t tb = 64u * (t >> 2) + ((t & 3u) ^ xterm_dev<SH>((t >> 2) << (6 - SH)));
     {
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdsp_fft1024_wave(C *__restrict__ 
         for (int j = 0; j < 16; j++)
             lds[a ^ ((4u * j) ^ xterm<SH>((uint32_t)j >> (SH - 2)))] = x[j];
     }
+    wave_lds_sync();
     // C: p = 16 w + i, p >> SH = w >> (SH - 4); w = reversed(t) so that the outputs land at t + 64 * reversed(i)
     {
         uint32_t a = (16u * w) ^ xterm_dev<SH>(w >> (SH - 4));
@@ -402,6 +416,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
             constexpr int I = decltype(from_tag)::value;
             constexpr uint32_t s_from = I == NP - 1 ? 1u : (uint32_t)N >> (LP * (I + 1));
             constexpr uint32_t s_to = I + 1 == NP - 1 ? 1u : (uint32_t)N >> (LP * (I + 2));
+            wave_lds_sync(); // the previous exchange's reads (other lanes') come first
             {
                 uint32_t a = a_of(from_tag);
                 asm volatile("" : "+v"(a)); // one v_xor per access instead of R live addresses
@@ -411,6 +426,7 @@ __global__ __launch_bounds__(256) void sdsp_fft_wave_f32(float2 *__restrict__ da
                     lds[g * N + (a ^ ((s_from * k) ^ xterm2<L>(s_from * k)))] = x[j];
                 }
             }
+            wave_lds_sync();
             {
                 uint32_t a = a_of(std::integral_constant<int, I + 1>{});
                 asm volatile("" : "+v"(a));

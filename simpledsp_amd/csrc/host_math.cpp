@@ -268,7 +268,12 @@ using namespace sdsp_hip;
 extern "C" {
 
 const char *sdsp_hip_last_error_string(void) { return g_last_error.c_str(); }
-const char *sdsp_hip_version(void) { return "sdsp-hip 0.1 (gfx950)"; }
+// SDSP_HIP_SOURCE_HASH: sha256 over csrc/ and include/ at build time (simpledsp_amd/build.py); the Python loader compares
+// it with the sources beside the library and refuses a stale .so
+#ifndef SDSP_HIP_SOURCE_HASH
+#define SDSP_HIP_SOURCE_HASH "unhashed"
+#endif
+const char *sdsp_hip_version(void) { return "sdsp-hip 0.3 (gfx950) src:" SDSP_HIP_SOURCE_HASH; }
 
 // fft.h:12-19
 unsigned sdsp_hip_log2(unsigned num)

@@ -18,6 +18,8 @@
 // current tile is computed.  Coefficients live in SGPRs (kernel arguments).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <string>
 #include <utility>
 
 #include "sdsp_hip_internal.h"
@@ -393,6 +395,157 @@ __global__ __launch_bounds__(64) void sdsp_iir_wide_kernel(iir_dev_args<typename
         store_state<R, M>(p, my_ch, y1, y2, y3);
 }
 
+// ---- LDS-DMA ring variant (round 3).  One wave per workgroup owns 64 channels, as above, but the tile never passes
+// through the register file on its way in: `global_load_lds_dwordx4` writes a [64 channels x RB bytes] tile straight into
+// one of SLOTS LDS slots (1 KiB of LDS per wave instruction: 64 / CPR rows x RB contiguous bytes of each), the lane filters
+// its own row IN PLACE in LDS, and only the finished tile is read back (lane-linear, conflict-free) for the streaming
+// stores.  So the loads of tile t + SLOTS - 1 are in flight while tile t is being filtered: the wave's memory pipeline has
+// no empty phase, and the registers hold one row's worth of samples instead of the 128-VGPR staging tile.
+//
+// LDS image: an LDS-DMA instruction's destination is M0 + 16 * lane, i.e. lane-linear, and only the SOURCE address is
+// per-lane (cdna_hip_programming.md, rule 21).  The 16-byte chunk at (row r, position c) of a slot therefore holds the
+// row's chunk c ^ f(r): the swizzle sits on the source address of the fill, on the lane's own row reads / writes, and on
+// the destination address of the stores.  f makes the row-per-lane ds_read_b128 (lane groups {0-3,12-15,20-27}, ... of
+// MI355X_MICROARCH.md's LDS table; bank = (a / 4) mod 64) and the ds_write_b128 (8 contiguous lanes, mod 32) conflict-free:
+// f(r) = r mod 16 for rows of 256 / 512 bytes, (r / 2) mod 8 for rows of 128 bytes.
+//
+// Ordering (hipcc does not count asm loads): a slot is read only behind an explicit `s_waitcnt vmcnt(W)`, W = the
+// vector-memory operations issued after that slot's fill (later fills and the stores of the tiles in between; all counted
+// in issue order); a slot is refilled only after its read-back has been consumed by the stores in front of the refill.
+template <int RB, bool SWZ = true> __device__ __forceinline__ constexpr int iir_dma_swz(int r)
+{
+    return !SWZ ? 0 : RB >= 256 ? (r & 15) : ((r >> 1) & 7);
+}
+
+template <bool NT> __device__ __forceinline__ void glds16(const void *uniform_base, uint32_t lane_off, uint32_t lds_dst)
+{
+    unsigned keep;
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(uniform_base), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(uniform_base), "s"(lds_dst)
+                     : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `groups` groups of NI operations are outstanding (capped at the counter's 63)
+template <int NI, int MAXG> __device__ __forceinline__ void wait_groups(int groups)
+{
+    if constexpr (MAXG == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (groups >= MAXG)
+            wait_vmcnt<(NI * MAXG > 63 ? 63 / NI * NI : NI * MAXG)>();
+        else
+            wait_groups<NI, MAXG - 1>(groups);
+    }
+}
+
+template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS, bool SWZ = true, bool FILL_FIRST = false>
+__global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
+{
+    // whole tiles only: channels a multiple of 64, samples a multiple of RB bytes (the launcher sends other shapes to the
+    // super-tile kernel: identical arithmetic)
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = typename vec16<S>::type;
+    constexpr int EPV = vec16<S>::n;
+    constexpr int CPR = RB / 16;  // 16-byte chunks per row of a tile = fills per tile
+    constexpr int RPI = 64 / CPR; // rows one fill instruction covers
+    constexpr int NI = CPR;
+    constexpr int TILE = 64 * RB;
+    constexpr int T = RB / (int)sizeof(S); // samples per tile row
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
+    const int lane = threadIdx.x;
+    const uint64_t ch0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t my_ch = ch0 + lane;
+
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, my_ch, y1, y2, y3);
+
+    const int q = lane / CPR, c = lane % CPR;
+    const uint64_t row_bytes = p.stride * sizeof(S);
+    const uint32_t lane_row = (uint32_t)(q * row_bytes); // the host checks the range
+    const char *const wg_base = reinterpret_cast<const char *>(p.data + ch0 * p.stride);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sdsp_iir_smem;
+    const uint64_t n_tiles = p.samples / T;
+    const int fl = iir_dma_swz<RB, SWZ>(lane);
+
+    // byte offset of this lane's chunk of fill / store instruction i from the instruction's uniform row base
+    auto lane_off = [&](int i) { return lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB, SWZ>(RPI * i + q)); };
+    auto fill = [&](uint64_t t, int slot) {
+        const char *tb = wg_base + t * RB;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            glds16<NT>(tb + (uint64_t)i * RPI * row_bytes, lane_off(i), lds0 + (uint32_t)(slot * TILE + i * 1024));
+    };
+
+    for (int s = 0; s < SLOTS; s++)
+        if ((uint64_t)s < n_tiles)
+            fill(s, s);
+    int slot = 0;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        // operations issued after tile t's fill: the stores of the tiles since (at most SLOTS - 1; FILL_FIRST: SLOTS, a
+        // refill goes out in front of the stores of the tile whose slot it takes) and the later fills
+        constexpr int SG = FILL_FIRST ? SLOTS : SLOTS - 1;
+        const uint64_t st = t < (uint64_t)SG ? t : (uint64_t)SG;
+        const uint64_t fl_after = n_tiles - 1 - t < (uint64_t)(SLOTS - 1) ? n_tiles - 1 - t : (uint64_t)(SLOTS - 1);
+        wait_groups<NI, SG + SLOTS - 1>((int)(st + fl_after));
+        unsigned char *const sl = sdsp_iir_smem + slot * TILE;
+        if constexpr (!PASS) {
+            unsigned char *const row = sl + lane * RB;
+            V x[CPR];
+#pragma unroll
+            for (int k = 0; k < CPR; k++)
+                x[k] = *reinterpret_cast<const V *>(row + 16 * (k ^ fl));
+#pragma unroll
+            for (int k = 0; k < CPR; k++) {
+                S *xe = reinterpret_cast<S *>(&x[k]);
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
+                *reinterpret_cast<V *>(row + 16 * (k ^ fl)) = x[k];
+            }
+        }
+        char *const tb = const_cast<char *>(wg_base) + t * RB;
+        if constexpr (FILL_FIRST) {
+            V v[NI];
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                v[i] = *reinterpret_cast<const V *>(sl + (i * 64 + lane) * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: it may be overwritten
+            if (t + SLOTS < n_tiles)
+                fill(t + SLOTS, slot);
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * RPI * row_bytes + lane_off(i)), v[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const V v = *reinterpret_cast<const V *>(sl + (i * 64 + lane) * 16);
+                gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * RPI * row_bytes + lane_off(i)), v);
+            }
+            if (t + SLOTS < n_tiles)
+                fill(t + SLOTS, slot);
+        }
+        slot = slot + 1 == SLOTS ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();
+    if (p.samples)
+        store_state<R, M>(p, my_ch, y1, y2, y3);
+}
+
 // ---- interleaved ("wire") layout, SURVEY 8(f)-2: data[s * stride + c], channels contiguous.  No
 // transpose at all: a lane owns VEC ADJACENT channels and runs their recurrences side by side
 // (independent dependency chains), a wave moves 64*VEC*sizeof(R) contiguous bytes of one sample row
@@ -518,10 +671,60 @@ template <typename P, int M> iir_dev_args<typename P::S, typename P::R, M> make_
     return p;
 }
 
+// the LDS-DMA ring kernel on whole tiles; SLOTS x 64 x RB bytes of LDS per one-wave workgroup
+template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS, bool SWZ = true, bool FF = false>
+int launch_dma(const iir_args &a, hipStream_t stream)
+{
+    const auto p = make_args<P, M>(a);
+    const uint64_t blocks = a.channels / 64;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    constexpr size_t lds = (size_t)SLOTS * 64 * RB;
+    static std::atomic<uint64_t> lds_ok{ 0 };
+    auto kern = sdsp_iir_dma_kernel<P, KIND, M, RB, SLOTS, NT, PASS, SWZ, FF>;
+    if (lds > 64 * 1024)
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_ok))
+            return rc;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(64), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
 template <typename P, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
 {
     const auto p = make_args<P, M>(a);
     using S = typename P::S;
+    // lab variants 10 .. 29 (f32 casc_2o_iir<4> only): the LDS-DMA ring kernel, 10 + shape: (RB, SLOTS) = (256, 2), (256, 3),
+    // (128, 4), (128, 3), (512, 2); +5: default cache policy on the fills; 20 ..: the same without the recurrence (copy)
+    if constexpr (sizeof(S) == 4 && sizeof(typename P::R) == 4 && KIND == SDSP_HIP_IIR_GENERIC && M == 4) {
+        const bool tiles = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) && a.channels % 64 == 0 &&
+                           (a.samples * sizeof(S)) % 512 == 0 && a.stride * sizeof(S) * 8 < (1ull << 32);
+        if (variant >= 10 && variant < 30 && tiles) {
+            switch (variant) {
+            case 10: return launch_dma<P, KIND, M, 256, 2, true, false>(a, stream);
+            case 11: return launch_dma<P, KIND, M, 256, 3, true, false>(a, stream);
+            case 12: return launch_dma<P, KIND, M, 128, 4, true, false>(a, stream);
+            case 13: return launch_dma<P, KIND, M, 128, 3, true, false>(a, stream);
+            case 14: return launch_dma<P, KIND, M, 128, 2, true, false>(a, stream);
+            case 15: return launch_dma<P, KIND, M, 256, 2, false, false>(a, stream);
+            case 16: return launch_dma<P, KIND, M, 256, 3, false, false>(a, stream);
+            case 20: return launch_dma<P, KIND, M, 256, 2, true, true>(a, stream);
+            case 21: return launch_dma<P, KIND, M, 256, 3, true, true>(a, stream);
+            case 22: return launch_dma<P, KIND, M, 128, 4, true, true>(a, stream);
+            case 23: return launch_dma<P, KIND, M, 128, 3, true, true>(a, stream);
+            case 24: return launch_dma<P, KIND, M, 128, 2, true, true>(a, stream);
+            case 25: return launch_dma<P, KIND, M, 256, 2, true, true, false>(a, stream);
+            case 26: return launch_dma<P, KIND, M, 128, 2, true, true, false>(a, stream);
+            case 27: return launch_dma<P, KIND, M, 128, 4, true, true, false>(a, stream);
+            case 28: return launch_dma<P, KIND, M, 256, 2, true, true, true, true>(a, stream);
+            case 29: return launch_dma<P, KIND, M, 256, 2, true, true, false, true>(a, stream);
+            case 17: return launch_dma<P, KIND, M, 256, 2, true, false, true, true>(a, stream);
+            default: break;
+            }
+        }
+    }
     const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) &&
                          ((a.samples * sizeof(S)) % 16 == 0);
     // variants (identical arithmetic, bit-identical results):

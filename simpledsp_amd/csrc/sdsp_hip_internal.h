@@ -153,6 +153,8 @@ struct fft1m_fused_args {
     void *workspace;     // ring x 2^20 complex
     const void *tw_1024; // W_1024^j
     void *sync;          // fft1m_sync_bytes(count) bytes of device memory (zeroed by the launcher)
+    void *sticky = nullptr;  // one word outside that block, or null: set to 1 by a launch that gave up, never cleared by the launcher
+    uint64_t spin_limit = 200000000ull; // wall_clock64 ticks (100 MHz) a hand-off poll may take: 2 s
     uint64_t count;
     uint32_t ring, lag;  // intermediate ring slots per queue; steps pass 2 trails pass 1 (lag < ring)
     uint32_t queues;     // independent ticket queues (workspace holds queues x ring transforms)

@@ -112,6 +112,16 @@ class FftPlan:
         """synchronise and raise if the plan's last launch gave up on a bounded in-kernel wait (N = 2^20 persistent kernel)"""
         L.check(self._lib.sdsp_hip_fft_plan_status(self._h))
 
+    def set_wait_limit(self, ticks: int):
+        """testing hook: bound of the N = 2^20 kernel's hand-off waits in 100 MHz ticks (default 2 s)"""
+        L.check(self._lib.sdsp_hip_fft_plan_set_wait_limit(self._h, ticks))
+
+    def launches(self, batch: int) -> int:
+        """kernel launches one exec of `batch` transforms issues (launch pieces and workspace slices included)"""
+        n = C.c_uint64()
+        L.check(self._lib.sdsp_hip_fft_plan_launches(self._h, batch, C.byref(n)))
+        return int(n.value)
+
     @property
     def info(self) -> L.PlanInfo:
         info = L.PlanInfo()
@@ -182,6 +192,11 @@ class RfftPlan:
 
     def set_variant(self, v: int):  # 0: the size's default kernel; 1 / 2: the register-pass family (A/B, cross-checks)
         L.check(self._lib.sdsp_hip_fft_plan_set_variant(self._h, v))
+
+    def launches(self, batch: int) -> int:
+        n = C.c_uint64()
+        L.check(self._lib.sdsp_hip_fft_plan_launches(self._h, batch, C.byref(n)))
+        return int(n.value)
 
     @property
     def info(self) -> L.PlanInfo:

