@@ -36,6 +36,7 @@ SOURCES = {
     "fft_reg.hip": ["-fno-slp-vectorize"],
     "fft_reg64.hip": ["-fno-slp-vectorize"],
     "fft_big.hip": ["-fno-slp-vectorize"],
+    "fft_big64.hip": ["-fno-slp-vectorize"],
     "fft_mix.hip": ["-fno-slp-vectorize"],
     "fft_wave.hip": ["-fno-slp-vectorize"],
     "fft_mid.hip": ["-fno-slp-vectorize"],

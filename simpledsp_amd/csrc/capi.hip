@@ -181,21 +181,19 @@ int upload_thread_twiddles_wave(const std::vector<double> &w, uint32_t n, int ra
 
 // Thread-twiddle table of fft_big.hip: [pass (A, B)][stage s < 5][thread t < N/32] = W^(t << s) for pass A,
 // W^((32 v) << s), v = t mod (N/1024), for pass B.
-int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, void **dev)
+int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, int precision, void **dev)
 {
     const uint32_t T = n / 32, vmask = n / 1024 - 1;
-    std::vector<float> tab((size_t)10 * T * 2);
+    std::vector<double> tab((size_t)10 * T * 2);
     for (uint32_t pass = 0; pass < 2; pass++)
         for (uint32_t s = 0; s < 5; s++)
             for (uint32_t t = 0; t < T; t++) {
                 const uint32_t idx = (pass == 0 ? t : 32 * (t & vmask)) << s;
                 const size_t o = ((size_t)(pass * 5 + s) * T + t) * 2;
-                tab[o] = (float)w[2 * (size_t)idx];
-                tab[o + 1] = (float)w[2 * (size_t)idx + 1];
+                tab[o] = w[2 * (size_t)idx];
+                tab[o + 1] = w[2 * (size_t)idx + 1];
             }
-    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    return SDSP_HIP_OK;
+    return upload_twiddles(tab, precision, dev); // rounds to the plan precision exactly like the row itself
 }
 
 // Thread-twiddle table of fft_big.hip's radix-4 form (N = 16384 = 4^7 and N = 4096 = 4^6, fft32_r4.h): [slot < 14][thread t < N/32].
@@ -232,6 +230,8 @@ inline bool big_r4_form(uint32_t n, int radix) { return radix == 4 && (n == 1638
 // (N = 8192, AUTO plans: fft_big.hip's radix-2 stages measured 76.9-77.9 % against 74.1-76.2 % for the mixed-radix kernel in one
 // run once their thread twiddles were fetched ahead of the passes, so they are variant 0 there too and fft_mix.hip variant 1)
 inline bool big_is_default(uint32_t n, int radix) { return big_r4_form(n, radix) || n == 8192; }
+// f64 radix-2 plans the double-precision registers-resident kernel serves: the variant number that selects it
+inline int big64_variant(uint32_t) { return 0; } // 4096: 73.2-73.6 % against 66.5-68.6 % (fft_reg64.hip), one call, round 3
 
 constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
@@ -398,7 +398,16 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
     // the register-pass family's MODE 1 / 2
     if (p->path == PATH_REG && f32 && variant == 0 && p->real_mode && p->twt_big && fft_big_real_supports(p->n, p->radix))
         return { K_BIG_REAL, "sdsp_fft_big_kernel", 1, big_r4_form(p->n, p->radix) ? 4 : 2, false, pc };
+    // double precision, radix-2 plans of N = 4096 / 8192 / 16384: the registers-resident kernel in double (fft_big64.hip).
+    // The default of all three sizes: 73.4 / 74.5 / 59.5 % of HBM peak against 67.5 % (N = 4096, fft_reg64.hip), 51.4 % (N = 8192:
+    // the whole tile in LDS) and 24.2 % (N = 16384: three streaming passes) in one call (tools/sweep_sizes64.py, round 3);
+    // what served a size before is its variant 1
+    const bool big64 = !f32 && !p->real_mode && p->twt_big && fft_big64_supports(p->n, p->radix);
+    if (big64 && variant == big64_variant(p->n))
+        return { K_BIG64, "sdsp_fft_big_f64_kernel", 1, 2, false, pc && p->n <= 4096 };
     if (p->path == PATH_REG && !f32) {
+        if (big64 && big64_variant(p->n) == 0) // the kernel that was the default becomes variant 1
+            variant = variant == 1 ? 0 : variant;
         const bool wave64 = !p->real_mode && fft_wave_supports(p->n, p->radix);
         if (variant == 1 && wave64) // N = 1024 alternate: same bits; measured 71.4-72.1 % against 71.7-72.6 %: no gain in double
             return { K_WAVE64, "sdsp_fft1024_wave", 1, p->radix, false, pc };
@@ -430,7 +439,7 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
     if (p->path == PATH_FOUR_STEP && variant == 0 && two_pass_size)
         return { K_2PASS, "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2, true, false };
     // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel (or, nested, on another plan)
-    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == (two_pass_size ? 1 : 0)) {
+    if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == ((two_pass_size || (big64 && big64_variant(p->n) == 0)) ? 1 : 0)) {
         const fft_kernel_sel rows = select_kernel(p->mid_rows, p->mid_rows->variant);
         // the column step is four radix-2 stages (fft_mid.hip), whatever runs in the rows
         return { K_MID, "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 2 + rows.hbm_passes,
@@ -492,6 +501,19 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.tw2 = p->tw2;
         }
         return launch_fft_big_f32(a, stream);
+    }
+    case K_BIG64: {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->twt_big;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = 1.0f;
+        a.scale_d = 1.0 / p->n;
+        a.reverse = rev;
+        a.nontemporal = 1;
+        return launch_fft_big_f64(a, stream);
     }
     case K_REG64:
     case K_WAVE64: {
@@ -898,7 +920,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                     (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))))
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && (fft_big_supports(n, radix) || fft_big_conv_supports(n, radix)))
-            rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, &p->twt_big);
+            rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big);
+        if (!rc && precision == SDSP_HIP_F64 && fft_big64_supports(n, radix))
+            rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
             rc = upload_thread_twiddles_wave(w, n, radix, &p->twt_wave);
         if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
@@ -922,7 +946,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         make_twiddles(n, direction, w);
         rc = upload_twiddles(w, precision, &p->tw);
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
-            rc = upload_thread_twiddles_big(w, n, &p->twt_big);
+            rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big);
+        if (!rc && precision == SDSP_HIP_F64 && fft_big64_supports(n, radix))
+            rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
         if (!rc) {
             make_twiddles(p->n1, direction, w);
             rc = upload_twiddles(w, precision, &p->tw1);
@@ -999,7 +1025,7 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
     std::vector<double> w;
     if (big_real && !p->twt_big) { // (every complex plan this kernel serves has the table already)
         make_twiddles(n, direction, w);
-        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, &p->twt_big)) {
+        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big)) {
             sdsp_hip_fft_plan_destroy(p);
             return rc;
         }

@@ -451,6 +451,15 @@ template <int NI, int MAXG> __device__ __forceinline__ void wait_groups(int grou
     }
 }
 
+// hipcc does not count asm loads: its own `s_waitcnt vmcnt(0)` for the state loads must sit in front of the first fill, not
+// at the state's first use inside the tile loop (where it would drain the fill in flight, every iteration)
+template <typename R, int M> __device__ __forceinline__ void settle_state(R (&y1)[M + 1], R (&y2)[M + 1], R (&y3)[M + 1])
+{
+#pragma unroll
+    for (int j = 0; j <= M; j++)
+        asm volatile("" : "+v"(y1[j]), "+v"(y2[j]), "+v"(y3[j]));
+}
+
 template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS, bool SWZ = true, bool FILL_FIRST = false>
 __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
@@ -473,6 +482,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
 
     R y1[M + 1], y2[M + 1], y3[M + 1];
     load_state<R, M>(p, my_ch, y1, y2, y3);
+    settle_state<R, M>(y1, y2, y3);
 
     const int q = lane / CPR, c = lane % CPR;
     const uint64_t row_bytes = p.stride * sizeof(S);
@@ -540,6 +550,118 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
                 fill(t + SLOTS, slot);
         }
         slot = slot + 1 == SLOTS ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();
+    if (p.samples)
+        store_state<R, M>(p, my_ch, y1, y2, y3);
+}
+
+// ---- landing-slot variant (round 3): the LDS-DMA fill of the kernel above with the super-tile kernel's burst shape.
+// What the ring kernel's lab runs established (profiles/r03_iir_lab.md): with 128- or 256-byte row segments per fill the
+// transport alone (no recurrence) stops at 59-61 % of HBM peak whatever the ring depth, occupancy, swizzle or issue order
+// -- the figure of the "one 128-byte piece per step" copy of DESIGN.md section 5: DRAM wants 512 contiguous bytes per
+// channel per burst.  A ring of 512-byte-row slots does not fit (2 x 32 KiB per wave = two waves per CU).  So this kernel
+// keeps ONE 32 KiB landing slot per wave: tile t's rows move from the slot into registers (row-per-lane, 128 VGPRs), the
+// slot is refilled with tile t + 1 AT ONCE -- it lands during the ~5 us recurrence of tile t -- and the results leave the
+// way the super-tile kernel's do: 128-byte pieces through an 8 KiB transpose buffer back into the same registers, then
+// row-group-major streaming stores (512 contiguous bytes per channel per burst).  40 KiB of LDS per one-wave workgroup:
+// four per CU, one per SIMD.
+template <typename P, int KIND, int M, bool NT, bool PASS, bool ILV = false>
+__global__ __launch_bounds__(64) void sdsp_iir_landing_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
+{
+    using S = typename P::S;
+    using R = typename P::R;
+    using V = typename vec16<S>::type;
+    constexpr int EPV = vec16<S>::n;
+    constexpr int RB = 512, CPR = RB / 16, RPI = 64 / CPR, NI = CPR, TILE = 64 * RB;
+    constexpr int T = RB / (int)sizeof(S); // samples per tile row
+    constexpr int PB = 128, PCH = PB / 16, NP = RB / PB; // output pieces: 128 bytes of a row, 8 chunks, 4 per tile
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
+    unsigned char *const land = sdsp_iir_smem;
+    unsigned char *const xp = sdsp_iir_smem + TILE; // 64 rows x 128 bytes, chunk k of row r at position k ^ ((r >> 1) & 7)
+    const int lane = threadIdx.x;
+    const uint64_t ch0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t my_ch = ch0 + lane;
+
+    R y1[M + 1], y2[M + 1], y3[M + 1];
+    load_state<R, M>(p, my_ch, y1, y2, y3);
+    settle_state<R, M>(y1, y2, y3);
+
+    const int q = lane / CPR, c = lane % CPR;
+    const uint64_t row_bytes = p.stride * sizeof(S);
+    const uint32_t lane_row = (uint32_t)(q * row_bytes); // the host checks the range
+    char *const wg_base = reinterpret_cast<char *>(p.data + ch0 * p.stride);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sdsp_iir_smem;
+    const uint64_t n_tiles = p.samples / T;
+    const int fl = iir_dma_swz<RB>(lane);
+
+    auto fill = [&](uint64_t t) {
+        const char *tb = wg_base + t * RB;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            glds16<NT>(tb + (uint64_t)i * RPI * row_bytes, lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB>(RPI * i + q)),
+                       lds0 + (uint32_t)(i * 1024));
+    };
+    // output side: store instruction (i, j) covers rows 8 i .. 8 i + 7, piece j; this lane: row 8 i + sub, position pc
+    const int sub = lane / PCH, pc = lane % PCH;
+    const uint32_t out_row = (uint32_t)(sub * row_bytes);
+    auto out_off = [&](int i) { return out_row + 16u * (uint32_t)(pc ^ iir_dma_swz<PB>(8 * i + sub)); };
+    const int fo = iir_dma_swz<PB>(lane);
+
+    if (n_tiles)
+        fill(0);
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        // behind tile t's fill: the stores of tile t - 1 (NP * 8 = 32 operations)
+        if (t == 0)
+            wait_vmcnt<0>();
+        else
+            wait_vmcnt<NP * 8>();
+        V x[CPR];
+        {
+            const unsigned char *const row = land + lane * RB;
+#pragma unroll
+            for (int k = 0; k < CPR; k++)
+                x[k] = *reinterpret_cast<const V *>(row + 16 * (k ^ fl));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: tile t + 1 may land
+        const bool more = t + 1 < n_tiles;
+        if (!ILV && more)
+            fill(t + 1);
+        if constexpr (!PASS) {
+            const char *const nb = wg_base + (t + 1) * RB;
+#pragma unroll
+            for (int k = 0; k < CPR; k++) {
+                S *xe = reinterpret_cast<S *>(&x[k]);
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
+                // ILV: one fill instruction behind every chunk's arithmetic, so that its issue (the address pass of 64 lanes x 16
+                // bytes) runs under the next chunk's VALU work instead of in a block of 32 in front of the recurrence
+                if (ILV && more)
+                    glds16<NT>(nb + (uint64_t)k * RPI * row_bytes, lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB>(RPI * k + q)),
+                               lds0 + (uint32_t)(k * 1024));
+            }
+        } else if (ILV && more) {
+            fill(t + 1);
+        }
+        // transpose piece by piece: x[8 j + k] (row = lane, chunk k of piece j)  ->  x[8 j + i] (row 8 i + sub, position pc)
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            unsigned char *const row = xp + lane * PB;
+#pragma unroll
+            for (int k = 0; k < PCH; k++)
+                *reinterpret_cast<V *>(row + 16 * (k ^ fo)) = x[PCH * j + k];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                x[PCH * j + i] = *reinterpret_cast<const V *>(xp + (i * 64 + lane) * 16);
+        }
+        char *const tb = wg_base + t * RB;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * 8 * row_bytes + j * PB + out_off(i)), x[PCH * j + i]);
     }
     wait_vmcnt<0>();
     if (p.samples)
@@ -692,17 +814,39 @@ int launch_dma(const iir_args &a, hipStream_t stream)
     return SDSP_HIP_OK;
 }
 
+// the landing-slot kernel on whole tiles; 40 KiB of LDS per one-wave workgroup
+template <typename P, int KIND, int M, bool PASS, bool ILV = false> int launch_landing(const iir_args &a, hipStream_t stream)
+{
+    const auto p = make_args<P, M>(a);
+    const uint64_t blocks = a.channels / 64;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    constexpr size_t lds = 64 * 512 + 64 * 128;
+    hipLaunchKernelGGL((sdsp_iir_landing_kernel<P, KIND, M, true, PASS, ILV>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+
 template <typename P, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
 {
     const auto p = make_args<P, M>(a);
     using S = typename P::S;
     // lab variants 10 .. 29 (f32 casc_2o_iir<4> only): the LDS-DMA ring kernel, 10 + shape: (RB, SLOTS) = (256, 2), (256, 3),
     // (128, 4), (128, 3), (512, 2); +5: default cache policy on the fills; 20 ..: the same without the recurrence (copy)
+    const bool tiles = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) && a.channels % 64 == 0 &&
+                       (a.samples * sizeof(S)) % 512 == 0 && a.stride * sizeof(S) * 8 < (1ull << 32);
+    if constexpr (KIND == SDSP_HIP_IIR_GENERIC && M == 4) {
+        if (tiles && variant == 18)
+            return launch_landing<P, KIND, M, false>(a, stream);
+        if (tiles && variant == 19)
+            return launch_landing<P, KIND, M, true>(a, stream);
+    }
     if constexpr (sizeof(S) == 4 && sizeof(typename P::R) == 4 && KIND == SDSP_HIP_IIR_GENERIC && M == 4) {
-        const bool tiles = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) && a.channels % 64 == 0 &&
-                           (a.samples * sizeof(S)) % 512 == 0 && a.stride * sizeof(S) * 8 < (1ull << 32);
-        if (variant >= 10 && variant < 30 && tiles) {
+        if (variant >= 9 && variant < 30 && tiles) {
             switch (variant) {
+            case 9: return launch_landing<P, KIND, M, false, true>(a, stream);
             case 10: return launch_dma<P, KIND, M, 256, 2, true, false>(a, stream);
             case 11: return launch_dma<P, KIND, M, 256, 3, true, false>(a, stream);
             case 12: return launch_dma<P, KIND, M, 128, 4, true, false>(a, stream);

@@ -302,13 +302,21 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x, radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=2)
+        if n == 1 << 14 and radix == 2:  # round 3: the registers-resident kernel in double is this size's default ...
+            assert plan.info.kernel.decode() == "sdsp_fft_big_f64_kernel" and plan.info.hbm_passes == 1
+            d0 = torch.from_numpy(x).cuda()
+            plan.exec(d0)
+            torch.cuda.synchronize()
+            assert rel_max_err(d0.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
+            plan.set_variant(1)  # ... and the three-pass schedule its variant 1
         assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
-        assert plan.info.hbm_passes == (3 if n < (1 << 18) else 5)
+        # N = 2^18 = 16 x 16384: its rows are one pass since the registers-resident kernel in double serves them (were three)
+        assert plan.info.hbm_passes == (3 if n <= (1 << 18) and not (n == 1 << 18 and radix == 4) else 5)
         d = torch.from_numpy(x).cuda()
         plan.exec(d)
         torch.cuda.synchronize()
         assert rel_max_err(d.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
-        plan.set_variant(1)  # the general four-step through the coverage kernel
+        plan.set_variant(2 if (n == 1 << 14 and radix == 2) else 1)  # the general four-step through the coverage kernel
         d2 = torch.from_numpy(x).cuda()
         plan.exec(d2)
         torch.cuda.synchronize()
@@ -368,10 +376,9 @@ def test_large_single_pass_kernel(sd, torch_cuda, oracle, n, batch):
 
 
 def test_fft1m_with_a_one_transform_workspace(sd, torch_cuda, oracle):
-    """A plan created with max_batch = 1 owns a single intermediate: the persistent kernel then runs with a ring of one
-    slot (pass 2 of a transform directly behind its pass 1, pass 1 of the next one waiting for the slot), the chunked
-    variant with chunks of one.  (Round 1's regression, found by tests/fuzz_crosscheck.py seed 31: a variant wrote past
-    such a workspace.)"""
+    """A plan created with max_batch = 1 owns a single intermediate: fewer than the 8 x 3 the persistent kernel needs, so
+    both variants of such a plan run the two-launch schedule, in chunks of one transform.  (Round 1's regression, found by
+    tests/fuzz_crosscheck.py seed 31: a variant wrote past such a workspace.)"""
     rng = np.random.default_rng(31)
     n = 1 << 20
     x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
@@ -380,6 +387,8 @@ def test_fft1m_with_a_one_transform_workspace(sd, torch_cuda, oracle):
         for variant in (0, 1):
             plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=1)
             plan.set_variant(variant)
+            assert plan.info.kernel.decode() == "sdsp_fft1m_cols+sdsp_fft1m_rows"
+            assert plan.launches(2) == 4  # two passes per chunk of one
             d = torch_cuda.from_numpy(x).cuda()
             guard = torch_cuda.full((1 << 16,), 7.0 + 3.0j, dtype=torch_cuda.complex64, device="cuda")
             plan.exec(d)
@@ -702,3 +711,159 @@ def test_convolve_launch_pieces_are_bit_identical(sd, torch_cuda, n, radix, prec
         assert torch.equal(torch.view_as_real(outs[0]), torch.view_as_real(outs[2]))
     finally:
         sd.set_launch_piece_bytes(old)
+
+
+# (n, radix, precision) -> (kernel, hbm_passes, stage_radix) of the DEFAULT variant: the size table of DESIGN.md section 1.
+# plan_get_info and exec read the same select_kernel() (csrc/capi.hip), so this table is what runs.
+STAGES_2_THEN_4 = 24
+SIZE_TABLE = [
+    (16, 2, "f32", "sdsp_fft_reg_kernel", 1, 2), (64, 4, "f32", "sdsp_fft_reg_kernel", 1, 4),
+    (256, 2, "f32", "sdsp_fft_wave_f32", 1, 2), (256, 4, "f32", "sdsp_fft_wave_f32", 1, 4),
+    (512, 2, "f32", "sdsp_fft_reg_kernel", 1, 2),
+    (1024, 2, "f32", "sdsp_fft1024_wave", 1, 2), (1024, 4, "f32", "sdsp_fft1024_wave", 1, 4),
+    (2048, 2, "f32", "sdsp_fft_wave_f32", 1, 2),
+    (4096, 2, "f32", "sdsp_fft4096_r2_f32", 1, 2), (4096, 4, "f32", "sdsp_fft4096_r4_f32", 1, 4),
+    (8192, 2, "f32", "sdsp_fft_big_kernel", 1, 2), (8192, 0, "f32", "sdsp_fft_big_kernel", 1, 2),
+    (16384, 2, "f32", "sdsp_fft_big_kernel", 1, 2), (16384, 4, "f32", "sdsp_fft_big_kernel", 1, 4),
+    (32768, 2, "f32", "sdsp_fft_big_kernel", 1, 2),
+    (1 << 16, 2, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2), (1 << 16, 4, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2),
+    (1 << 18, 4, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2), (1 << 19, 2, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2),
+    (1 << 20, 2, "f32", "sdsp_fft1m_fused", 2, 2), (1 << 20, 4, "f32", "sdsp_fft1m_fused", 2, 2),
+    (64, 4, "f64", "sdsp_fft_reg_f64_kernel", 1, 4), (1024, 2, "f64", "sdsp_fft_reg_f64_kernel", 1, 2),
+    (4096, 4, "f64", "sdsp_fft_reg_f64_kernel", 1, 4), (4096, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
+    (8192, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2), (16384, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
+    (16384, 4, "f64", "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 3, 24),
+]
+
+
+@pytest.mark.parametrize("n,batch", [(4096, 5), (8192, 1), (8192, 7), (16384, 3)])
+def test_registers_resident_kernel_f64(sd, torch_cuda, oracle, n, batch):
+    """fft_big64.hip (round 3): N = 4096 / 8192 / 16384 in double, transform in registers, one HBM pass; held to the
+    reference's own bound 4 N eps against the oracle in both directions, and to the kernel it replaces as the default."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n + batch)
+    x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
+    v_big = 0
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        want = oracle.fft(x, 2, rev)
+        plan = sd.FftPlan(n, 2, T, sd.F64, max_batch=batch)
+        plan.set_variant(v_big)
+        assert plan.info.kernel.decode() == "sdsp_fft_big_f64_kernel" and plan.info.hbm_passes == 1 and plan.info.stage_radix == 2
+        d = torch.from_numpy(x).cuda()
+        guard = torch.full((1 << 14,), 7.0 + 3.0j, dtype=torch.complex128, device="cuda")
+        plan.exec(d)
+        torch.cuda.synchronize()
+        got = d.cpu().numpy()
+        assert rel_max_err(got, want) < _tol64(n), (n, rev, rel_max_err(got, want))
+        assert bool((guard == 7.0 + 3.0j).all())
+        plan.set_variant(1 - v_big)  # what served the size before
+        assert plan.info.kernel.decode() != "sdsp_fft_big_f64_kernel"
+        d2 = torch.from_numpy(x).cuda()
+        plan.exec(d2)
+        torch.cuda.synchronize()
+        assert rel_max_err(d2.cpu().numpy(), got) < _tol64(n)
+
+
+@pytest.mark.parametrize("n,radix,precision,kernel,passes,stages", SIZE_TABLE)
+def test_plan_info_reports_the_kernel_and_stage_type_that_run(sd, torch_cuda, oracle, n, radix, precision, kernel, passes, stages):
+    """round 2 verdict, next #6: `info.stage_radix` is the butterfly type of the kernel that exec dispatches to (one table for
+    both), an explicit radix-4 plan above N = 16384 says that its default kernel runs radix-2 butterflies, and variant 8 of
+    such a plan (the coverage kernel) runs -- and reports -- genuine radix-4 stages; all of them are held to the oracle of the
+    plan's radix."""
+    torch = torch_cuda
+    prec = sd.F64 if precision == "f64" else sd.F32
+    plan = sd.FftPlan(n, radix, sd.forward_fft, prec, max_batch=32)
+    info = plan.info
+    assert info.kernel.decode() == kernel
+    assert info.hbm_passes == passes
+    assert info.stage_radix == stages
+    assert info.radix == (radix or (4 if sd.isPowerOf4(n) and n != 16384 else 2))  # the plan's own (validated) radix
+    rng = np.random.default_rng(n + radix)
+    x = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))).astype(np.complex128 if precision == "f64" else np.complex64)
+    want = oracle.fft(x.astype(np.complex128), info.radix) if n <= 1 << 16 else np.fft.fft(x.astype(np.complex128), axis=-1)
+    d = torch.from_numpy(x).cuda()
+    plan.exec(d)
+    torch.cuda.synchronize()
+    assert rel_max_err(d.cpu().numpy(), want) < (TOL32 if precision == "f32" else _tol64(n))
+    if radix == 4 and n >= 1 << 16:
+        plan.set_variant(8)
+        info = plan.info
+        assert info.kernel.decode() == "sdsp_fft_tile_kernel" and info.stage_radix == 4
+        d = torch.from_numpy(x).cuda()
+        plan.exec(d)
+        torch.cuda.synchronize()
+        assert rel_max_err(d.cpu().numpy(), want) < TOL32
+
+
+def test_mixed_radix_plan_reports_two_then_four(sd, torch_cuda):
+    plan = sd.FftPlan(8192, 0, sd.forward_fft, sd.F32, max_batch=4)
+    plan.set_variant(1)
+    info = plan.info
+    assert info.kernel.decode() == "sdsp_fft_mix_f32" and info.stage_radix == STAGES_2_THEN_4
+
+
+def test_launch_count_query(sd, torch_cuda):
+    """sdsp_hip_fft_plan_launches: what bench.py divides a step by (it used to re-derive the piece count by hand)"""
+    piece = sd.get_launch_piece_bytes()
+    try:
+        sd.set_launch_piece_bytes(1 << 30)
+        p = sd.FftPlan(4096, 4, sd.forward_fft, sd.F32, max_batch=16)
+        assert p.launches(65536) == 2 and p.launches(262144) == 8 and p.launches(40000) == 1 and p.launches(0) == 0
+        assert sd.FftPlan(16384, 2, sd.forward_fft, sd.F32, max_batch=16).launches(1 << 14) == 1  # never in pieces
+        assert sd.FftPlan(1 << 20, 2, sd.forward_fft, sd.F32, max_batch=256).launches(256) == 1
+        p2 = sd.FftPlan(1 << 16, 2, sd.forward_fft, sd.F32, max_batch=2048)
+        assert p2.launches(2048) == 2 * 4  # chunks of 2^25 / n = 512 transforms, two passes each
+        sd.set_launch_piece_bytes(0)
+        assert p.launches(262144) == 1
+    finally:
+        sd.set_launch_piece_bytes(piece)
+
+
+def test_fft1m_lost_handoff_is_reported(sd, torch_cuda):
+    """a persistent N = 2^20 launch whose bounded hand-off wait gives up used to return OK from
+    exec_host with invalid output.  With the wait bound forced to zero ticks every wait that has to poll gives up: the
+    synchronous host entry must return an error, the asynchronous one must leave it for status(), and a later healthy call
+    must clear it."""
+    torch = torch_cuda
+    n, batch = 1 << 20, 32
+    plan = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch)
+    assert plan.info.kernel.decode() == "sdsp_fft1m_fused"
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    plan.set_wait_limit(0)
+    with pytest.raises(sd.SdspHipError) as e:
+        plan.exec_host(x.copy())
+    assert "gave up" in str(e.value)
+    d = torch.from_numpy(x).cuda()
+    plan.exec(d)  # asynchronous: returns OK ...
+    with pytest.raises(sd.SdspHipError):
+        plan.status()  # ... and the caller learns here
+    plan.set_wait_limit(200_000_000)
+    y = x.copy()
+    plan.exec_host(y)  # a healthy call clears the sticky word and computes the right thing
+    plan.status()
+    want = np.fft.fft(x[[0, batch - 1]].astype(np.complex128), axis=-1)
+    assert rel_max_err(y[[0, batch - 1]], want) < TOL32
+
+
+def test_bench_under_torch_distributed_run_on_one_gpu(sd, torch_cuda):
+    """round 2 verdict, next #8: the N-rank path of bench.py (RCCL process group, throw-away barrier, barrier + max over
+    ranks around the timed steps, ONE JSON line from rank 0) runs here as a FRESH child process tree under
+    torch.distributed.run with one rank -- never an exec of this process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SDSP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29713", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-other-configs",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["batch_per_gpu"] == 65536 and out["roofline"]["launches_per_step"] == 2
+    assert 0.5 < out["roofline"]["frac"] < 0.9, out["roofline"]

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "fft1m_kernels.h"
@@ -217,7 +218,8 @@ int main(int argc, char **argv)
     const size_t n = (size_t)g_batch << 20;
     CK(hipMalloc(&g_data, n * 8));
     CK(hipMalloc(&g_ref, n * 8));
-    CK(hipMalloc(&g_ws, (size_t)32 << 23));
+    const bool ring_mode = argc > 2 && std::string(argv[2]) == "ring";
+    CK(hipMalloc(&g_ws, (size_t)(ring_mode ? 128 : 32) << 23));
     CK(hipMalloc(&g_tw, 1024 * 8));
     CK(hipMalloc(&g_sync, fused_sync_words(g_batch, 16) * 4));
     std::vector<float2> tw(1024);
@@ -226,6 +228,33 @@ int main(int argc, char **argv)
         tw[j] = float2{ (float)std::cos(a), (float)std::sin(a) };
     }
     CK(hipMemcpy(g_tw, tw.data(), 1024 * 8, hipMemcpyHostToDevice));
+
+    if (ring_mode) {
+        // round 2 verdict, next #9: where does the intermediate live?  The same persistent launch (sc1 stores, acquire + plain
+        // loads: the product's) with the intermediate ring sized from 8 to 128 transforms = 64 MiB .. 1 GiB, i.e. from well
+        // inside the 256 MiB Infinity Cache to four times its size; per-transform time against ring bytes shows the knee.
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, g_data, n, 99u);
+        const shape shapes[] = { { 8, 1, 0, 2 }, { 8, 2, 1, 2 }, { 8, 3, 1, 2 }, { 8, 4, 2, 2 }, { 8, 6, 4, 2 }, { 8, 8, 6, 2 },
+                                 { 8, 12, 10, 2 }, { 8, 16, 14, 2 }, { 8, 8, 2, 2 }, { 8, 16, 2, 2 }, { 16, 8, 6, 2 } };
+        for (int rep = 0; rep < 2; rep++)
+            for (auto &sh : shapes) {
+                char buf[200];
+                g_flags = 1; // sc1 stores carry no release fence
+                const double ms = time_it([&](bool rev) {
+                    if (rev)
+                        fused<true, MODE_FFT, WS_BLOCKED | WS_SC1_STORES>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
+                    else
+                        fused<false, MODE_FFT, WS_BLOCKED | WS_SC1_STORES>(g_data, g_batch, sh.ring, sh.lag, sh.per_cu, sh.queues);
+                });
+                std::snprintf(buf, sizeof buf, "ring: queues %2u x ring %2u (lag %2u) = %3u intermediates = %4u MiB, %.2f us per transform",
+                              sh.queues, sh.ring, sh.lag, sh.queues * sh.ring, sh.queues * sh.ring * 8, ms * 1e3 / g_batch);
+                report(buf, ms);
+                if (read_abort())
+                    std::printf("   ^^^ ABORTED\n");
+            }
+        g_flags = 0;
+        return 0;
+    }
 
     // ---- exhaustive checks of the persistent schedule: every element of every transform against the two-launch
     // schedule, launches back to back (warm caches, the ring re-used at once), batch sizes that leave queues uneven

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <vector>
 
-template <int RB> __device__ __forceinline__ constexpr int swz(int r) { return RB >= 256 ? (r & 15) : ((r >> 1) & 7); }
+template <int RB> __host__ __device__ constexpr int swz(int r) { return RB >= 256 ? (r & 15) : ((r >> 1) & 7); }
 
 __device__ __forceinline__ void glds16(const void *base, uint32_t off, uint32_t dst)
 {

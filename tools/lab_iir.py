@@ -33,7 +33,7 @@ for v in [0] + [v for v in variants if v != 0]:
     if v == 0:
         ref = y
     else:
-        same = torch.equal(y, ref) or v >= 20  # 20 ..: copy-only lab variants
+        same = torch.equal(y, ref) or v >= 19  # 19 ..: copy-only lab variants
         print(f"variant {v}: {'bit-identical to variant 0' if torch.equal(y, ref) else 'DIFFERENT from variant 0'}", flush=True)
         if not same:
             bad = (y != ref).nonzero()
@@ -46,7 +46,7 @@ x = torch.randn((channels, samples), generator=g, device="cuda", dtype=dt)
 if len(sys.argv) > 5 and sys.argv[5] == "check":
     keep = x.clone()
     want = None
-    for v in [0] + [v for v in variants if 0 < v < 20]:
+    for v in [0] + [v for v in variants if 0 < v < 19]:
         b = sd.casc_2o_iir(4, channels, prec, sd.IIR_GENERIC)
         b.set_lp_coeff(10e3, 100e3)
         b.set_variant(v)
