@@ -177,7 +177,8 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int r
  * ASYNCHRONOUS callers of n = 2^20 plans (sdsp_hip_fft_exec) must call this before trusting the output.  Has no reference
  * counterpart. */
 int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
-/* Testing hook for the error path above: the bound of the hand-off waits in 100 MHz ticks (default 200 000 000 = 2 s). */
+/* Testing hook for the error path above: the bound of the hand-off waits in 100 MHz ticks (default 200 000 000 = 2 s);
+ * 0 = fault injection: every hand-off wait of the next launches gives up at once (their output is invalid by construction). */
 int sdsp_hip_fft_plan_set_wait_limit(sdsp_hip_fft_plan *plan, uint64_t ticks);
 /* Kernel launches that one sdsp_hip_fft_exec(plan, data, batch) issues with the plan's current variant (launch pieces and
  * workspace slices included; memsets not counted).  For profilers and bench.py: per-launch bytes = batch x
@@ -290,7 +291,15 @@ int sdsp_hip_iir_process_sharded(sdsp_hip_iir_plan *const *plans, int n_plans, v
                                  uint64_t channels, uint64_t samples);
 /* bytes of a state buffer for `channels` channels */
 int sdsp_hip_iir_state_bytes(const sdsp_hip_iir_plan *plan, uint64_t channels, uint64_t *bytes);
+/* kernel variants of sdsp_hip_iir_process (tuning / testing; identical arithmetic, bit-identical results): 0 = default -- the
+ * landing-slot kernel (LDS-DMA fill one tile ahead of the recurrence) for f32 banks of up to 4 sections on whole [64
+ * channels x 512 bytes] tiles, the super-tile kernel for everything else; 1 = wide super-tile; 2 = direct (any alignment);
+ * 3 = super-tile.  DESIGN.md section 5.4. */
 int sdsp_hip_iir_plan_set_variant(sdsp_hip_iir_plan *plan, int variant);
+/* name of the kernel sdsp_hip_iir_process would launch for this buffer shape with the plan's variant (for matching
+ * rocprofv3 rows); the same selection function as the launcher's.  Has no reference counterpart. */
+int sdsp_hip_iir_plan_kernel(const sdsp_hip_iir_plan *plan, const void *data, uint64_t channels, uint64_t samples,
+                             uint64_t stride, char *name, size_t name_bytes);
 
 /* ------------------------------------------------------------------ FIR filter bank */
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "sdsp_hip_iir_process_sharded": (_i, [_pp, _i, _vp, _u64, _u64]),
     "sdsp_hip_iir_state_bytes": (_i, [_vp, _u64, C.POINTER(_u64)]),
     "sdsp_hip_iir_plan_set_variant": (_i, [_vp, _i]),
+    "sdsp_hip_iir_plan_kernel": (_i, [_vp, _vp, _u64, _u64, _u64, C.c_char_p, _sz]),
     "sdsp_hip_fir_design": (_i, [_u32, _i, _d, _d, _d, _d, _vp]),
     "sdsp_hip_fir_plan_create": (_i, [_pp, _u32, _vp, _i, _i]),
     "sdsp_hip_fir_plan_destroy": (_i, [_vp]),

@@ -338,7 +338,10 @@ int ensure_workspace(sdsp_hip_fft_plan *p)
 
 // chunk sizes of the multi-pass schedules (shared by exec and the launch count)
 uint64_t fft1m_chunk(const sdsp_hip_fft_plan *p) { return std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch)); }
-uint64_t fft2p_chunk(const sdsp_hip_fft_plan *p) { return std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 25) / p->n)); }
+uint64_t fft2p_chunk(const sdsp_hip_fft_plan *p) // an intermediate of at most 256 MiB per chunk
+{
+    return std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 28) / ((uint64_t)p->n * esize(p->precision))));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // The ONE dispatch table: which kernel serves (plan, variant).  sdsp_hip_fft_exec, sdsp_hip_fft_plan_get_info and
@@ -435,7 +438,7 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
             return { K_FFT1M_CHUNKED, "sdsp_fft1m_cols+sdsp_fft1m_rows", 2, 2, true, false };
         return { K_FFT1M_FUSED, "sdsp_fft1m_fused", 2, 2, true, false };
     }
-    const bool two_pass_size = f32 && fft_2pass_supports(p->n);
+    const bool two_pass_size = fft_2pass_supports(p->n, p->precision);
     if (p->path == PATH_FOUR_STEP && variant == 0 && two_pass_size)
         return { K_2PASS, "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2, true, false };
     // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel (or, nested, on another plan)
@@ -627,14 +630,15 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         const uint64_t chunk = fft2p_chunk(p);
         for (uint64_t done = 0; done < batch; done += chunk) {
             fft_2pass_args a;
-            a.data = reinterpret_cast<char *>(data) + done * p->n * 8;
+            a.data = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
             a.workspace = p->workspace;
             a.tw_1024 = p->tw1024;
             a.n = p->n;
             a.count = std::min<uint64_t>(chunk, batch - done);
             a.scale = (float)(1.0 / p->n);
+            a.scale_d = 1.0 / p->n;
             a.reverse = rev;
-            if (int rc = launch_fft_2pass_f32(a, stream))
+            if (int rc = launch_fft_2pass(p->precision, a, stream))
                 return rc;
         }
         return SDSP_HIP_OK;
@@ -1422,6 +1426,23 @@ int sdsp_hip_iir_process(sdsp_hip_iir_plan *p, void *data, uint64_t channels, ui
         a.b2[j] = p->b[3 * j + 2];
     }
     return launch_iir(p->precision, a, p->variant, stream);
+}
+
+int sdsp_hip_iir_plan_kernel(const sdsp_hip_iir_plan *p, const void *data, uint64_t channels, uint64_t samples, uint64_t stride,
+                             char *name, size_t name_bytes)
+{
+    if (!p || !name || name_bytes == 0)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "null argument");
+    iir_args a{};
+    a.data = const_cast<void *>(data);
+    a.channels = channels;
+    a.samples = samples;
+    a.stride = stride;
+    a.sections = p->sections;
+    a.kind = p->kind;
+    std::strncpy(name, iir_kernel_for(p->precision, a, p->variant), name_bytes - 1);
+    name[name_bytes - 1] = 0;
+    return SDSP_HIP_OK;
 }
 
 int sdsp_hip_iir_process_interleaved(sdsp_hip_iir_plan *p, void *data, uint64_t channels, uint64_t samples,

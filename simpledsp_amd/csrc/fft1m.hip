@@ -89,7 +89,7 @@ template <bool REV, int LAYOUT> int launch_fused_t(const fft1m_fused_args &a, hi
     k.ring = a.ring;
     k.lag = a.lag;
     k.queues = a.queues;
-    k.flags = 0;
+    k.flags = a.spin_limit == 0 ? 8u : 0u; // a bound of zero ticks = fault injection: every hand-off wait gives up (tests)
     k.sleep = 0;
     k.scale = a.scale;
     k.sticky = reinterpret_cast<unsigned *>(a.sticky);

@@ -356,7 +356,8 @@ struct fused_args {
     unsigned *sync;
     unsigned *sticky;   // nullable: set to 1 by a launch that gives up; the host clears it once per API call, not per launch
     uint32_t count, ring, lag, queues;
-    uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence, 4 = queue = XCD id
+    uint32_t flags;     // lab only: 1 = no release fence, 2 = no acquire fence, 4 = queue = XCD id; 8 = fault injection (tests):
+                        // every hand-off wait gives up at once
     uint32_t sleep;     // s_sleep argument of the polls is fixed; this many extra sleeps per poll iteration
     float scale;
     unsigned long long spin_limit; // wall_clock64 ticks (100 MHz) a poll may take before it gives up
@@ -446,7 +447,15 @@ __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)
             wait_word = done + 32 * (xf - a.ring * a.queues) + 16; // the ring slot's previous tenant has been read
         if (wait_word) {
             if (threadIdx.x == 0) {
-                const bool ok = poll_geq(wait_word, kTiles, abort_flag, a.sticky, a.spin_limit, a.sleep);
+                bool ok;
+                if (a.flags & 8u) { // injected fault: behave exactly like a poll whose bound expired
+                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.sticky)
+                        __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                } else {
+                    ok = poll_geq(wait_word, kTiles, abort_flag, a.sticky, a.spin_limit, a.sleep);
+                }
                 if (!(a.flags & 2u)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -32,6 +32,26 @@ __device__ __forceinline__ float2 *at(float2 *base, uint32_t byte_off)
 {
     return reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off);
 }
+// the same helpers for complex doubles (the two-pass kernels in double, fft_2pass.hip)
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load(const double2 *p)
+{
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return double2{ v.x, v.y };
+}
+__device__ __forceinline__ void nt_store(double2 *p, double2 a)
+{
+    const v2d_t v = { a.x, a.y };
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t *>(p));
+}
+__device__ __forceinline__ const double2 *at(const double2 *base, uint32_t byte_off)
+{
+    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ double2 *at(double2 *base, uint32_t byte_off)
+{
+    return reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + byte_off);
+}
 // Rows of one transform through a buffer resource: `buffer_load/store_dwordx2 v, voffset, s[rsrc], soffset offen` takes the
 // row's byte offset in an SGPR (any size) next to ONE per-thread VGPR offset.  With rows 4-8 KiB apart -- beyond the 13-bit
 // immediate of global_load -- the compiler builds a 64-bit VGPR address per row from plain pointers however they are written
@@ -66,6 +86,12 @@ __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return float2{
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return float2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
+}
+__device__ __forceinline__ double2 operator+(double2 a, double2 b) { return double2{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ double2 operator-(double2 a, double2 b) { return double2{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return double2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
 }
 
 // cos / sin of 2*pi*j/32, j < 16
@@ -102,6 +128,51 @@ __device__ constexpr float kS32[16] = { 0.0f,
                                         0.38268343236508977173f,
                                         0.19509032201612826785f };
 
+// the same table in double (correctly rounded), and the accessor that picks the table of a complex type's scalar
+__device__ constexpr double kC32d[16] = { 1.0,
+                                          0.98078528040323044913,
+                                          0.92387953251128675613,
+                                          0.83146961230254523708,
+                                          0.70710678118654752440,
+                                          0.55557023301960222474,
+                                          0.38268343236508977173,
+                                          0.19509032201612826785,
+                                          0.0,
+                                          -0.19509032201612826785,
+                                          -0.38268343236508977173,
+                                          -0.55557023301960222474,
+                                          -0.70710678118654752440,
+                                          -0.83146961230254523708,
+                                          -0.92387953251128675613,
+                                          -0.98078528040323044913 };
+__device__ constexpr double kS32d[16] = { 0.0,
+                                          0.19509032201612826785,
+                                          0.38268343236508977173,
+                                          0.55557023301960222474,
+                                          0.70710678118654752440,
+                                          0.83146961230254523708,
+                                          0.92387953251128675613,
+                                          0.98078528040323044913,
+                                          1.0,
+                                          0.98078528040323044913,
+                                          0.92387953251128675613,
+                                          0.83146961230254523708,
+                                          0.70710678118654752440,
+                                          0.55557023301960222474,
+                                          0.38268343236508977173,
+                                          0.19509032201612826785 };
+template <typename C> struct w32;
+template <> struct w32<float2> {
+    using real = float;
+    static __device__ constexpr float c(int e) { return kC32[e]; }
+    static __device__ constexpr float s(int e) { return kS32[e]; }
+};
+template <> struct w32<double2> {
+    using real = double;
+    static __device__ constexpr double c(int e) { return kC32d[e]; }
+    static __device__ constexpr double s(int e) { return kS32d[e]; }
+};
+
 // Five radix-2 DIF stages on 32 registers: x[k] is the element at base + k*stride.  Stage s pairs
 // (k, k + h), h = 16 >> s.  The lower output owes the twiddle W_{2H}^(pos mod H) (fft.h:286 applies
 // the same factor on the DIT side); it factors into the thread's w[s] (absent when TW is false) and
@@ -113,13 +184,14 @@ __device__ constexpr float kS32[16] = { 0.0f,
 // stage s reads wsrc[s * u] (coalesced across lanes) instead of gathering wsrc[u << s] from the row W^j.
 // CONJ: the table holds the other direction's values (the fused convolution runs its reverse transform on the forward
 // plan's table): conjugate what is fetched.
-template <bool REV, bool TW, int S0 = 0, bool TABLE = false, bool CONJ = false>
-__device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, uint32_t u)
+template <bool REV, bool TW, int S0 = 0, bool TABLE = false, bool CONJ = false, typename C = float2>
+__device__ __forceinline__ void fft32_dif(C (&x)[32], const C *wsrc, uint32_t u)
 {
+    using R = typename w32<C>::real;
 #pragma unroll
     for (int s = S0; s < 5; s++) {
         const int h = 16 >> s;
-        float2 ws = float2{ 1.0f, 0.0f };
+        C ws = C{ R(1), R(0) };
         if constexpr (TW) {
             ws = TABLE ? wsrc[s * u] : wsrc[u << s];
             if constexpr (CONJ)
@@ -129,15 +201,15 @@ __device__ __forceinline__ void fft32_dif(float2 (&x)[32], const float2 *wsrc, u
         for (int k = 0; k < 32; k++) {
             if ((k & h) != 0)
                 continue;
-            const float2 a = x[k], b = x[k + h];
+            const C a = x[k], b = x[k + h];
             x[k] = a + b;
-            float2 d = a - b;
+            C d = a - b;
             const int e = (k & (h - 1)) << s; // W_32 exponent, 0..15
             if (e == 8) {
-                d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x }; // -i / +i by swap and negate
+                d = REV ? C{ -d.y, d.x } : C{ d.y, -d.x }; // -i / +i by swap and negate
             } else if (e != 0) {
-                const float cr = kC32[e], ci = REV ? kS32[e] : -kS32[e];
-                d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
+                const R cr = w32<C>::c(e), ci = REV ? w32<C>::s(e) : -w32<C>::s(e);
+                d = C{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
             }
             if constexpr (TW)
                 d = cmul(d, ws);

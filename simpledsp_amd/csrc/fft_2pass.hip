@@ -1,4 +1,5 @@
-// fft_2pass.hip -- batched N = 2^16 .. 2^19 complex f32 FFT in TWO passes over HBM, for gfx950: the tile scheme of the
+// fft_2pass.hip -- batched N = 2^16 .. 2^19 complex f32 FFT (and, round 3, N = 2^16 .. 2^20 in double: the same templates
+// on double2) in TWO passes over HBM, for gfx950: the tile scheme of the
 // N = 2^20 kernels (fft1m_kernels.h) generalised to N = N1 x N2 with N1, N2 in {256, 512, 1024}.
 //
 // Radix-2 butterfly stages of sdsp::fft_radix2 (fft.h:276-294) as a four-step decomposition, the transform viewed as a
@@ -35,7 +36,8 @@ constexpr int kTile = 16; // sequences per tile
 
 template <int BITS> __device__ __forceinline__ uint32_t brev_bits(uint32_t v) { return BITS == 0 ? 0u : (__brev(v) >> (32 - BITS)); }
 
-// W_N^m, N = 2^L, m < N: coarse factor from the LDS copy of W_1024, fine factor (angle < 2 pi / 1024) from two series terms
+// W_N^m, N = 2^L, m < N: coarse factor from the LDS copy of W_1024, fine factor (angle < 2 pi / 1024) from a short series:
+// two terms are exact to fp32; double takes the terms up to th^6 / 720 and th^7 / 5040 (< 1e-19 relative)
 template <int L, bool REV> __device__ __forceinline__ float2 twiddle_n(const float2 *w1k, uint32_t m)
 {
     constexpr int FB = L - 10; // fine bits
@@ -45,22 +47,33 @@ template <int L, bool REV> __device__ __forceinline__ float2 twiddle_n(const flo
     const float2 fine = float2{ 1.0f - 0.5f * th2, REV ? sn : -sn };
     return cmul(w1k[m >> FB], fine);
 }
+template <int L, bool REV> __device__ __forceinline__ double2 twiddle_n(const double2 *w1k, uint32_t m)
+{
+    constexpr int FB = L - 10;
+    const double th = (double)(m & ((1u << FB) - 1u)) * (6.283185307179586476925 / (double)(1u << L));
+    const double t2 = th * th;
+    const double cs = 1.0 - t2 * (0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0)));
+    const double sn = th * (1.0 - t2 * (1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0))));
+    const double2 fine = double2{ cs, REV ? sn : -sn };
+    return cmul(w1k[m >> FB], fine);
+}
 
 // ---- pass 1: 16 columns of one transform; 16 * T1 threads ----------------------------------------------------
 // in_x / ws_x: the transform's input matrix / its intermediate.  LDS: plane N1 x 16 floats, w1k = W_1024 (8 KiB, staged by
 // the caller), qtab 32 x 16 float2 (4 KiB)
-template <int L, int L1, bool REV>
-__device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, uint32_t tile, float *plane, const float2 *w1k, float2 *qtab)
+template <int L, int L1, bool REV, typename C>
+__device__ __forceinline__ void cols_tile2p(const C *in_x, C *ws_x, uint32_t tile, typename w32<C>::real *plane, const C *w1k, C *qtab)
 {
+    using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32;
     const uint32_t t = threadIdx.x;
     const uint32_t c = t & 15, u = t >> 4; // u < T1
     const uint32_t n2 = tile * kTile + c;
 
     // rows u + T1 k of column n2
-    const float2 *src_tile = in_x + tile * kTile;
-    const uint32_t toff = (u * N2 + c) * 8u;
-    float2 x[32];
+    const C *src_tile = in_x + tile * kTile;
+    const uint32_t toff = (u * N2 + c) * (uint32_t)sizeof(C);
+    C x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
         x[k] = nt_load(at(src_tile + (size_t)T1 * N2 * k, toff));
@@ -76,11 +89,11 @@ __device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, ui
 
     // exchange rows {u + T1 k} -> {32 u + k}; slot(row, col) = (row * 16 + col) ^ (((row >> 5) & 1) << 4)
     {
-        float *const w0 = plane + (u * 16 + c);
-        float *const w1 = plane + ((u * 16 + c) ^ 16);
+        Real *const w0 = plane + (u * 16 + c);
+        Real *const w1 = plane + ((u * 16 + c) ^ 16);
         const int flip = (int)(u & 1) * 16;
-        const float *const r_even = plane + (512 * u + c) + flip;
-        const float *const r_odd = plane + (512 * u + c) - flip;
+        const Real *const r_even = plane + (512 * u + c) + flip;
+        const Real *const r_odd = plane + (512 * u + c) - flip;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll
@@ -89,7 +102,7 @@ __device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, ui
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const float f = ((k & 1) ? r_odd : r_even)[16 * k];
+                const Real f = ((k & 1) ? r_odd : r_even)[16 * k];
                 if (half)
                     x[k].y = f;
                 else
@@ -103,10 +116,10 @@ __device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, ui
 
     // row 32 u + k holds Y[k1], k1 = bit_reverse_L1(32 u + k) = (bit_reverse5(k) << (L1 - 5)) | bit_reverse(u)
     const uint32_t bu = brev_bits<L1 - 5>(u);
-    const float2 pw = twiddle_n<L, REV>(w1k, n2 * bu);
-    const float2 *const qcol = qtab + c;
-    float2 *dst_tile = ws_x + (size_t)tile * (N1 * kTile); // [tile][k1][c]
-    const uint32_t soff = (bu * 16 + c) * 8u;
+    const C pw = twiddle_n<L, REV>(w1k, n2 * bu);
+    const C *const qcol = qtab + c;
+    C *dst_tile = ws_x + (size_t)tile * (N1 * kTile); // [tile][k1][c]
+    const uint32_t soff = (bu * 16 + c) * (uint32_t)sizeof(C);
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0)
@@ -115,50 +128,56 @@ __device__ __forceinline__ void cols_tile2p(const float2 *in_x, float2 *ws_x, ui
         *at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff) = cmul(x[k], cmul(pw, qcol[16 * j]));
     }
 }
-__device__ __forceinline__ void stage_w1k2p(float2 *w1k, const float2 *tw_1024, uint32_t threads)
+template <typename C> __device__ __forceinline__ void stage_w1k2p(C *w1k, const C *tw_1024, uint32_t threads)
 {
-    for (uint32_t i = threadIdx.x; i < 512; i += threads)
+    // 16-byte copies: two f32 twiddles / one f64 twiddle each
+    constexpr uint32_t n16 = 1024 * sizeof(C) / 16;
+    for (uint32_t i = threadIdx.x; i < n16; i += threads)
         reinterpret_cast<float4 *>(w1k)[i] = reinterpret_cast<const float4 *>(tw_1024)[i];
 }
-template <int L, int L1, bool REV>
-__global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const float2 *__restrict__ in, float2 *__restrict__ ws,
-                                                                          const float2 *__restrict__ tw_1024)
+template <int L, int L1, bool REV, typename C>
+__global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const C *__restrict__ in, C *__restrict__ ws,
+                                                                          const C *__restrict__ tw_1024)
 {
+    using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32, THREADS = kTile * T1, TILES = N2 / kTile;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
-    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
-    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(float));
+    Real *plane = reinterpret_cast<Real *>(sdsp_fft2p_smem);
+    C *w1k = reinterpret_cast<C *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(Real));
     stage_w1k2p(w1k, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    cols_tile2p<L, L1, REV>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024);
+    cols_tile2p<L, L1, REV, C>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024);
 }
 
 // ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
 // LDS: plane 16 x N2 floats; wrow = pass 2's thread twiddles [stage][lane] (5 x 32 float2, staged by the caller)
-template <int L, int L1, bool REV>
-__device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *wrow, float scale)
+template <int L, int L1, bool REV, typename C>
+__device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t tile, typename w32<C>::real *plane, const C *wrow,
+                                            typename w32<C>::real scale)
 {
+    using Real = typename w32<C>::real;
+    constexpr uint32_t ES = (uint32_t)sizeof(C);
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32;
     const uint32_t t = threadIdx.x;
 
     // first register pass: T2 lanes run along a row; element n2 = ua + T2 k of row k1 = 16 tile + ra lives at
     // [(n2 >> 4)][k1][n2 & 15] of the intermediate
     const uint32_t ra = t / T2, ua = t % T2;
-    const float2 *src = ws_x + (size_t)tile * (kTile * kTile);
-    float2 x[32];
+    const C *src = ws_x + (size_t)tile * (kTile * kTile);
+    C x[32];
     if constexpr (T2 == 32) {
-        const uint32_t aoff = ((ua >> 4) * (N1 * kTile) + ra * 16 + (ua & 15)) * 8u;
+        const uint32_t aoff = ((ua >> 4) * (N1 * kTile) + ra * 16 + (ua & 15)) * ES;
 #pragma unroll
         for (int k = 0; k < 32; k++)
             x[k] = *at(src + (size_t)2 * k * (N1 * kTile), aoff);
     } else if constexpr (T2 == 16) {
-        const uint32_t aoff = (ra * 16 + ua) * 8u;
+        const uint32_t aoff = (ra * 16 + ua) * ES;
 #pragma unroll
         for (int k = 0; k < 32; k++)
             x[k] = *at(src + (size_t)k * (N1 * kTile), aoff);
     } else {
         static_assert(T2 == 8, "row length 256, 512 or 1024");
-        const uint32_t aoff = (ra * 16 + ua) * 8u;
+        const uint32_t aoff = (ra * 16 + ua) * ES;
 #pragma unroll
         for (int k = 0; k < 32; k++)
             x[k] = *at(src + (size_t)(k >> 1) * (N1 * kTile) + 8 * (k & 1), aoff);
@@ -171,7 +190,7 @@ __device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, u
     // write pos = ua + T2 k of row ra; read pos = 32 ub + k of row rb
     const uint32_t rb = t & 15, ub = t >> 4; // ub < T2
     {
-        float *wb0, *wb1; // bases of the writes; the per-k part is a compile-time offset
+        Real *wb0, *wb1; // bases of the writes; the per-k part is a compile-time offset
         if constexpr (T2 == 32) { // low 5 bits of pos = ua; bit 5 = k & 1
             wb0 = plane + ra * N2 + (ua ^ ra);
             wb1 = plane + ra * N2 + (ua ^ ra ^ 16);
@@ -181,13 +200,13 @@ __device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, u
             wb0 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (ra >> 3);       // k even: bit 3 = 0 ^ (ra >> 3)
             wb1 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (1 - (ra >> 3)); // k odd:  bit 3 = 1 ^ (ra >> 3)
         }
-        const float *const r_base = plane + rb * N2 + 32 * ub;
+        const Real *const r_base = plane + rb * N2 + 32 * ub;
         const uint32_t rx = rb | ((ub & 1) << 4);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const float f = half ? x[k].y : x[k].x;
+                const Real f = half ? x[k].y : x[k].x;
                 if constexpr (T2 == 32)
                     ((k & 1) ? wb1 : wb0)[32 * k] = f;
                 else if constexpr (T2 == 16)
@@ -201,7 +220,7 @@ __device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, u
                 asm volatile("" : "+v"(q)); // the 32 XOR'ed addresses are rebuilt, not kept in registers
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
-                    const float f = r_base[k ^ q];
+                    const Real f = r_base[k ^ q];
                     if (half)
                         x[k].y = f;
                     else
@@ -216,14 +235,14 @@ __device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, u
 
     // position 32 ub + k of row k1 holds X[k1 + N1 k2], k2 = (bit_reverse5(k) << (L2 - 5)) | bit_reverse(ub): 16 lanes write
     // 128 contiguous bytes (streaming store of the final result)
-    float2 *dst_tile = out_x + tile * kTile;
+    C *dst_tile = out_x + tile * kTile;
     const uint32_t bub = brev_bits<L2 - 5>(ub);
-    const uint32_t boff = (bub * N1 + rb) * 8u;
+    const uint32_t boff = (bub * N1 + rb) * ES;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         if ((k & 7) == 0)
             __builtin_amdgcn_sched_barrier(0);
-        float2 v = x[k];
+        C v = x[k];
         if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
             v.x *= scale;
             v.y *= scale;
@@ -232,67 +251,88 @@ __device__ __forceinline__ void rows_tile2p(const float2 *ws_x, float2 *out_x, u
     }
 }
 // [stage][lane] = W_N2^(lane << stage) = W_1024^((lane 1024/N2) << stage)
-template <int L2> __device__ __forceinline__ void stage_wrow2p(float2 *wrow, const float2 *tw_1024, uint32_t threads)
+template <int L2, typename C> __device__ __forceinline__ void stage_wrow2p(C *wrow, const C *tw_1024, uint32_t threads)
 {
+    using Real = typename w32<C>::real;
     constexpr int N2 = 1 << L2, T2 = N2 / 32;
     for (uint32_t i = threadIdx.x; i < 5 * 32; i += threads)
-        wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : float2{ 1.0f, 0.0f };
+        wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : C{ Real(1), Real(0) };
 }
-template <int L, int L1, bool REV>
-__global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const float2 *__restrict__ ws, float2 *__restrict__ out,
-                                                                              const float2 *__restrict__ tw_1024, float scale)
+template <int L, int L1, bool REV, typename C>
+__global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const C *__restrict__ ws, C *__restrict__ out,
+                                                                              const C *__restrict__ tw_1024, typename w32<C>::real scale)
 {
+    using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32, THREADS = kTile * T2, TILES = N1 / kTile;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
-    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
-    float2 *wrow = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(float));
+    Real *plane = reinterpret_cast<Real *>(sdsp_fft2p_smem);
+    C *wrow = reinterpret_cast<C *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(Real));
     stage_wrow2p<L2>(wrow, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    rows_tile2p<L, L1, REV>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
+    rows_tile2p<L, L1, REV, C>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
 }
 
-template <int L, int L1, bool REV> int launch_pair(const fft_2pass_args &a, hipStream_t s)
+template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_args &a, hipStream_t s)
 {
+    using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
-    constexpr size_t lds_cols = (size_t)N1 * kTile * 4 + 1024 * 8 + 32 * kTile * 8;
-    constexpr size_t lds_rows = (size_t)N2 * kTile * 4 + 5 * 32 * 8;
+    constexpr size_t lds_cols = (size_t)N1 * kTile * sizeof(Real) + 1024 * sizeof(C) + 32 * kTile * sizeof(C);
+    constexpr size_t lds_rows = (size_t)N2 * kTile * sizeof(Real) + 5 * 32 * sizeof(C);
     static std::atomic<uint64_t> done_c{ 0 }, done_r{ 0 };
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_cols<L, L1, REV>), lds_cols, done_c))
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_cols<L, L1, REV, C>), lds_cols, done_c))
         return rc;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows<L, L1, REV>), lds_rows, done_r))
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows<L, L1, REV, C>), lds_rows, done_r))
         return rc;
     const uint64_t blocks_c = a.count * (N2 / kTile), blocks_r = a.count * (N1 / kTile);
     if (blocks_c > 0x7fffffffull || blocks_r > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
-    float2 *d = reinterpret_cast<float2 *>(a.data), *ws = reinterpret_cast<float2 *>(a.workspace);
-    const float2 *tw = reinterpret_cast<const float2 *>(a.tw_1024);
-    hipLaunchKernelGGL((sdsp_fft2p_cols<L, L1, REV>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
-    hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, a.scale);
+    C *d = reinterpret_cast<C *>(a.data), *ws = reinterpret_cast<C *>(a.workspace);
+    const C *tw = reinterpret_cast<const C *>(a.tw_1024);
+    const Real scale = sizeof(Real) == 8 ? (Real)a.scale_d : (Real)a.scale;
+    hipLaunchKernelGGL((sdsp_fft2p_cols<L, L1, REV, C>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
+    hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV, C>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
-template <int L, int L1> int launch_dir(const fft_2pass_args &a, hipStream_t s)
+template <int L, int L1, typename C> int launch_dir(const fft_2pass_args &a, hipStream_t s)
 {
-    return a.reverse ? launch_pair<L, L1, true>(a, s) : launch_pair<L, L1, false>(a, s);
+    return a.reverse ? launch_pair<L, L1, true, C>(a, s) : launch_pair<L, L1, false, C>(a, s);
 }
 } // namespace
 
-bool fft_2pass_supports(uint32_t n) { return n >= (1u << 16) && n <= (1u << 19) && sdsp_hip_is_power_of_2(n); }
+// f32: N = 2^16 .. 2^19 (2^20 has the persistent kernel of fft1m.hip); f64: N = 2^16 .. 2^20
+bool fft_2pass_supports(uint32_t n, int precision)
+{
+    if (!sdsp_hip_is_power_of_2(n) || n < (1u << 16))
+        return false;
+    return n <= (precision == SDSP_HIP_F64 ? (1u << 20) : (1u << 19));
+}
 
 // both passes over one chunk of `count` transforms (the workspace holds `count` intermediates)
-int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream)
+int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream)
 {
     if (a.count == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (precision == SDSP_HIP_F64) {
+        switch (a.n) {
+        case 1u << 16: return launch_dir<16, 8, double2>(a, s);  //  256 x  256
+        case 1u << 17: return launch_dir<17, 8, double2>(a, s);  //  256 x  512
+        case 1u << 18: return launch_dir<18, 9, double2>(a, s);  //  512 x  512
+        case 1u << 19: return launch_dir<19, 9, double2>(a, s);  //  512 x 1024
+        case 1u << 20: return launch_dir<20, 10, double2>(a, s); // 1024 x 1024
+        default: break;
+        }
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
+    }
     switch (a.n) {
     // N1 x N2: the longer factor goes to pass 2, whose exchange writes are conflict-free at N2 = 1024 only
-    case 1u << 16: return launch_dir<16, 8>(a, s);  //  256 x  256
-    case 1u << 17: return launch_dir<17, 8>(a, s);  //  256 x  512
-    case 1u << 18: return launch_dir<18, 9>(a, s);  //  512 x  512
-    case 1u << 19: return launch_dir<19, 9>(a, s);  //  512 x 1024
+    case 1u << 16: return launch_dir<16, 8, float2>(a, s);  //  256 x  256
+    case 1u << 17: return launch_dir<17, 8, float2>(a, s);  //  256 x  512
+    case 1u << 18: return launch_dir<18, 9, float2>(a, s);  //  512 x  512
+    case 1u << 19: return launch_dir<19, 9, float2>(a, s);  //  512 x 1024
     default: break;
     }
     return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");

@@ -412,9 +412,9 @@ __global__ __launch_bounds__(64) void sdsp_iir_wide_kernel(iir_dev_args<typename
 // Ordering (hipcc does not count asm loads): a slot is read only behind an explicit `s_waitcnt vmcnt(W)`, W = the
 // vector-memory operations issued after that slot's fill (later fills and the stores of the tiles in between; all counted
 // in issue order); a slot is refilled only after its read-back has been consumed by the stores in front of the refill.
-template <int RB, bool SWZ = true> __device__ __forceinline__ constexpr int iir_dma_swz(int r)
+template <int RB> __device__ __forceinline__ constexpr int iir_dma_swz(int r)
 {
-    return !SWZ ? 0 : RB >= 256 ? (r & 15) : ((r >> 1) & 7);
+    return RB >= 256 ? (r & 15) : ((r >> 1) & 7);
 }
 
 template <bool NT> __device__ __forceinline__ void glds16(const void *uniform_base, uint32_t lane_off, uint32_t lds_dst)
@@ -460,7 +460,7 @@ template <typename R, int M> __device__ __forceinline__ void settle_state(R (&y1
         asm volatile("" : "+v"(y1[j]), "+v"(y2[j]), "+v"(y3[j]));
 }
 
-template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS, bool SWZ = true, bool FILL_FIRST = false>
+template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS>
 __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
     // whole tiles only: channels a multiple of 64, samples a multiple of RB bytes (the launcher sends other shapes to the
@@ -490,10 +490,10 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
     const char *const wg_base = reinterpret_cast<const char *>(p.data + ch0 * p.stride);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sdsp_iir_smem;
     const uint64_t n_tiles = p.samples / T;
-    const int fl = iir_dma_swz<RB, SWZ>(lane);
+    const int fl = iir_dma_swz<RB>(lane);
 
     // byte offset of this lane's chunk of fill / store instruction i from the instruction's uniform row base
-    auto lane_off = [&](int i) { return lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB, SWZ>(RPI * i + q)); };
+    auto lane_off = [&](int i) { return lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB>(RPI * i + q)); };
     auto fill = [&](uint64_t t, int slot) {
         const char *tb = wg_base + t * RB;
 #pragma unroll
@@ -506,12 +506,10 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
             fill(s, s);
     int slot = 0;
     for (uint64_t t = 0; t < n_tiles; t++) {
-        // operations issued after tile t's fill: the stores of the tiles since (at most SLOTS - 1; FILL_FIRST: SLOTS, a
-        // refill goes out in front of the stores of the tile whose slot it takes) and the later fills
-        constexpr int SG = FILL_FIRST ? SLOTS : SLOTS - 1;
-        const uint64_t st = t < (uint64_t)SG ? t : (uint64_t)SG;
+        // operations issued after tile t's fill: the stores of the tiles since (at most SLOTS - 1) and the later fills
+        const uint64_t st = t < (uint64_t)(SLOTS - 1) ? t : (uint64_t)(SLOTS - 1);
         const uint64_t fl_after = n_tiles - 1 - t < (uint64_t)(SLOTS - 1) ? n_tiles - 1 - t : (uint64_t)(SLOTS - 1);
-        wait_groups<NI, SG + SLOTS - 1>((int)(st + fl_after));
+        wait_groups<NI, 2 * (SLOTS - 1)>((int)(st + fl_after));
         unsigned char *const sl = sdsp_iir_smem + slot * TILE;
         if constexpr (!PASS) {
             unsigned char *const row = sl + lane * RB;
@@ -529,26 +527,13 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
             }
         }
         char *const tb = const_cast<char *>(wg_base) + t * RB;
-        if constexpr (FILL_FIRST) {
-            V v[NI];
 #pragma unroll
-            for (int i = 0; i < NI; i++)
-                v[i] = *reinterpret_cast<const V *>(sl + (i * 64 + lane) * 16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: it may be overwritten
-            if (t + SLOTS < n_tiles)
-                fill(t + SLOTS, slot);
-#pragma unroll
-            for (int i = 0; i < NI; i++)
-                gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * RPI * row_bytes + lane_off(i)), v[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const V v = *reinterpret_cast<const V *>(sl + (i * 64 + lane) * 16);
-                gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * RPI * row_bytes + lane_off(i)), v);
-            }
-            if (t + SLOTS < n_tiles)
-                fill(t + SLOTS, slot);
+        for (int i = 0; i < NI; i++) {
+            const V v = *reinterpret_cast<const V *>(sl + (i * 64 + lane) * 16);
+            gstore16<S, true>(reinterpret_cast<S *>(tb + (uint64_t)i * RPI * row_bytes + lane_off(i)), v);
         }
+        if (t + SLOTS < n_tiles) // (the refill in FRONT of these stores measured the same: 59.0 against 56.9-59.1 %)
+            fill(t + SLOTS, slot);
         slot = slot + 1 == SLOTS ? 0 : slot + 1;
     }
     wait_vmcnt<0>();
@@ -566,7 +551,7 @@ __global__ __launch_bounds__(64) void sdsp_iir_dma_kernel(iir_dev_args<typename 
 // way the super-tile kernel's do: 128-byte pieces through an 8 KiB transpose buffer back into the same registers, then
 // row-group-major streaming stores (512 contiguous bytes per channel per burst).  40 KiB of LDS per one-wave workgroup:
 // four per CU, one per SIMD.
-template <typename P, int KIND, int M, bool NT, bool PASS, bool ILV = false>
+template <typename P, int KIND, int M, bool NT, bool PASS>
 __global__ __launch_bounds__(64) void sdsp_iir_landing_kernel(iir_dev_args<typename P::S, typename P::R, M> p)
 {
     using S = typename P::S;
@@ -625,25 +610,18 @@ __global__ __launch_bounds__(64) void sdsp_iir_landing_kernel(iir_dev_args<typen
                 x[k] = *reinterpret_cast<const V *>(row + 16 * (k ^ fl));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: tile t + 1 may land
-        const bool more = t + 1 < n_tiles;
-        if (!ILV && more)
+        if (t + 1 < n_tiles)
             fill(t + 1);
+        // (one fill instruction behind every chunk's arithmetic instead of 32 in a block here measured the same: 70.8-71.1 %
+        // against 70.5-71.0 %, profiles/r03_iir_lab.md)
         if constexpr (!PASS) {
-            const char *const nb = wg_base + (t + 1) * RB;
 #pragma unroll
             for (int k = 0; k < CPR; k++) {
                 S *xe = reinterpret_cast<S *>(&x[k]);
 #pragma unroll
                 for (int e = 0; e < EPV; e++)
                     xe[e] = (S)cascade_step<R, KIND, M, P::fused>((R)xe[e], p, y1, y2, y3);
-                // ILV: one fill instruction behind every chunk's arithmetic, so that its issue (the address pass of 64 lanes x 16
-                // bytes) runs under the next chunk's VALU work instead of in a block of 32 in front of the recurrence
-                if (ILV && more)
-                    glds16<NT>(nb + (uint64_t)k * RPI * row_bytes, lane_row + 16u * (uint32_t)(c ^ iir_dma_swz<RB>(RPI * k + q)),
-                               lds0 + (uint32_t)(k * 1024));
             }
-        } else if (ILV && more) {
-            fill(t + 1);
         }
         // transpose piece by piece: x[8 j + k] (row = lane, chunk k of piece j)  ->  x[8 j + i] (row 8 i + sub, position pc)
 #pragma unroll
@@ -794,7 +772,7 @@ template <typename P, int M> iir_dev_args<typename P::S, typename P::R, M> make_
 }
 
 // the LDS-DMA ring kernel on whole tiles; SLOTS x 64 x RB bytes of LDS per one-wave workgroup
-template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS, bool SWZ = true, bool FF = false>
+template <typename P, int KIND, int M, int RB, int SLOTS, bool NT, bool PASS>
 int launch_dma(const iir_args &a, hipStream_t stream)
 {
     const auto p = make_args<P, M>(a);
@@ -803,7 +781,7 @@ int launch_dma(const iir_args &a, hipStream_t stream)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
     constexpr size_t lds = (size_t)SLOTS * 64 * RB;
     static std::atomic<uint64_t> lds_ok{ 0 };
-    auto kern = sdsp_iir_dma_kernel<P, KIND, M, RB, SLOTS, NT, PASS, SWZ, FF>;
+    auto kern = sdsp_iir_dma_kernel<P, KIND, M, RB, SLOTS, NT, PASS>;
     if (lds > 64 * 1024)
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_ok))
             return rc;
@@ -815,87 +793,101 @@ int launch_dma(const iir_args &a, hipStream_t stream)
 }
 
 // the landing-slot kernel on whole tiles; 40 KiB of LDS per one-wave workgroup
-template <typename P, int KIND, int M, bool PASS, bool ILV = false> int launch_landing(const iir_args &a, hipStream_t stream)
+template <typename P, int KIND, int M, bool PASS> int launch_landing(const iir_args &a, hipStream_t stream)
 {
     const auto p = make_args<P, M>(a);
     const uint64_t blocks = a.channels / 64;
     if (blocks > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
     constexpr size_t lds = 64 * 512 + 64 * 128;
-    hipLaunchKernelGGL((sdsp_iir_landing_kernel<P, KIND, M, true, PASS, ILV>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
+    hipLaunchKernelGGL((sdsp_iir_landing_kernel<P, KIND, M, true, PASS>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("iir launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
 
-template <typename P, int KIND, int M> int launch_km(const iir_args &a, int variant, hipStream_t stream)
+// ---- which kernel serves (precision, sections, shape, variant): ONE function, used by the launcher and by the name query
+// (sdsp_hip_iir_plan_kernel) that bench.py / the profiles match rocprofv3 rows with.
+//   variant 0  default: the landing-slot kernel where it measured faster -- f32 recurrences of m_t <= 4 on whole tiles
+//              (70.6-71.1 % against 69.9-70.1 % for the super-tile kernel, cfg 4, one call, three times; in double and in the
+//              mixed mode its one wave per SIMD is VALU-bound: 68.3 / 64.6 % against 71.8 / 67.5 %) -- else the super-tile kernel
+//   variant 1  wide super-tile (512 contiguous bytes per instruction); whole super-tiles only, else as variant 3
+//   variant 2  direct kernel (lane = channel, scalar accesses): any alignment, any length
+//   variant 3  super-tile kernel (round 2's default)
+//   variants 10 / 19 / 20 (lab, f32 casc_2o_iir<4> only): LDS-DMA ring 256 B x 2; landing slot and ring without the recurrence
+// Shapes the vector kernels cannot address (not 16-byte aligned) run the direct kernel whatever the variant.
+enum iir_kernel_id { IIR_K_SUPERTILE, IIR_K_WIDE, IIR_K_DIRECT, IIR_K_LANDING, IIR_K_RING_LAB, IIR_K_LANDING_COPY_LAB, IIR_K_RING_COPY_LAB, IIR_K_BAD };
+
+const char *iir_kernel_name(iir_kernel_id id)
+{
+    switch (id) {
+    case IIR_K_SUPERTILE: return "sdsp_iir_supertile_kernel";
+    case IIR_K_WIDE: return "sdsp_iir_wide_kernel";
+    case IIR_K_DIRECT: return "sdsp_iir_direct_kernel";
+    case IIR_K_LANDING:
+    case IIR_K_LANDING_COPY_LAB: return "sdsp_iir_landing_kernel";
+    case IIR_K_RING_LAB:
+    case IIR_K_RING_COPY_LAB: return "sdsp_iir_dma_kernel";
+    default: return "none";
+    }
+}
+
+iir_kernel_id iir_select(int precision, const iir_args &a, int variant)
+{
+    const size_t ss = precision == SDSP_HIP_F64 ? 8 : 4; // sample size (the mixed mode stores floats)
+    if (a.sections > 8)
+        return IIR_K_DIRECT; // m_t = 10 .. 16: correct, not tuned
+    const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * ss) % 16 == 0) && ((a.samples * ss) % 16 == 0);
+    if (variant == 2 || !aligned)
+        return IIR_K_DIRECT;
+    // whole [64 channels x 512 bytes] tiles, per-lane row offsets within 32 bits
+    const bool tiles = a.channels % 64 == 0 && (a.samples * ss) % 512 == 0 && a.stride * ss * 8 < (1ull << 32);
+    const bool lab = precision == SDSP_HIP_F32 && a.kind == SDSP_HIP_IIR_GENERIC && a.sections == 4 && tiles;
+    switch (variant) {
+    case 0: return (precision == SDSP_HIP_F32 && a.sections <= 4 && tiles) ? IIR_K_LANDING : IIR_K_SUPERTILE;
+    case 1: return (tiles && (a.stride + 128) * ss < (1ull << 32)) ? IIR_K_WIDE : IIR_K_SUPERTILE;
+    case 3: return IIR_K_SUPERTILE;
+    case 10: return lab ? IIR_K_RING_LAB : IIR_K_BAD;
+    case 19: return lab ? IIR_K_LANDING_COPY_LAB : IIR_K_BAD;
+    case 20: return lab ? IIR_K_RING_COPY_LAB : IIR_K_BAD;
+    default: return IIR_K_BAD;
+    }
+}
+
+template <typename P, int KIND, int M> int launch_km(const iir_args &a, iir_kernel_id id, hipStream_t stream)
 {
     const auto p = make_args<P, M>(a);
-    using S = typename P::S;
-    // lab variants 10 .. 29 (f32 casc_2o_iir<4> only): the LDS-DMA ring kernel, 10 + shape: (RB, SLOTS) = (256, 2), (256, 3),
-    // (128, 4), (128, 3), (512, 2); +5: default cache policy on the fills; 20 ..: the same without the recurrence (copy)
-    const bool tiles = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) && a.channels % 64 == 0 &&
-                       (a.samples * sizeof(S)) % 512 == 0 && a.stride * sizeof(S) * 8 < (1ull << 32);
-    if constexpr (KIND == SDSP_HIP_IIR_GENERIC && M == 4) {
-        if (tiles && variant == 18)
-            return launch_landing<P, KIND, M, false>(a, stream);
-        if (tiles && variant == 19)
-            return launch_landing<P, KIND, M, true>(a, stream);
-    }
-    if constexpr (sizeof(S) == 4 && sizeof(typename P::R) == 4 && KIND == SDSP_HIP_IIR_GENERIC && M == 4) {
-        if (variant >= 9 && variant < 30 && tiles) {
-            switch (variant) {
-            case 9: return launch_landing<P, KIND, M, false, true>(a, stream);
-            case 10: return launch_dma<P, KIND, M, 256, 2, true, false>(a, stream);
-            case 11: return launch_dma<P, KIND, M, 256, 3, true, false>(a, stream);
-            case 12: return launch_dma<P, KIND, M, 128, 4, true, false>(a, stream);
-            case 13: return launch_dma<P, KIND, M, 128, 3, true, false>(a, stream);
-            case 14: return launch_dma<P, KIND, M, 128, 2, true, false>(a, stream);
-            case 15: return launch_dma<P, KIND, M, 256, 2, false, false>(a, stream);
-            case 16: return launch_dma<P, KIND, M, 256, 3, false, false>(a, stream);
-            case 20: return launch_dma<P, KIND, M, 256, 2, true, true>(a, stream);
-            case 21: return launch_dma<P, KIND, M, 256, 3, true, true>(a, stream);
-            case 22: return launch_dma<P, KIND, M, 128, 4, true, true>(a, stream);
-            case 23: return launch_dma<P, KIND, M, 128, 3, true, true>(a, stream);
-            case 24: return launch_dma<P, KIND, M, 128, 2, true, true>(a, stream);
-            case 25: return launch_dma<P, KIND, M, 256, 2, true, true, false>(a, stream);
-            case 26: return launch_dma<P, KIND, M, 128, 2, true, true, false>(a, stream);
-            case 27: return launch_dma<P, KIND, M, 128, 4, true, true, false>(a, stream);
-            case 28: return launch_dma<P, KIND, M, 256, 2, true, true, true, true>(a, stream);
-            case 29: return launch_dma<P, KIND, M, 256, 2, true, true, false, true>(a, stream);
-            case 17: return launch_dma<P, KIND, M, 256, 2, true, false, true, true>(a, stream);
-            default: break;
-            }
-        }
-    }
-    const bool aligned = ((uintptr_t)a.data % 16 == 0) && ((a.stride * sizeof(S)) % 16 == 0) &&
-                         ((a.samples * sizeof(S)) % 16 == 0);
-    // variants (identical arithmetic, bit-identical results):
-    //   0 super-tile, streaming accesses (default)   1 wide super-tile (512 contiguous bytes per instruction)   2 direct
-    // Measured and dropped (round 1, BASELINE config 4, f32): super-tile with the default cache policy 66 % (0: 70 %), of 3 / 2
-    // sub-tiles (384- / 256-byte bursts) 61.9 / 58.8 %, four-wave tiles with 128- / 256-byte rows 61 / 56 %.
-    if (variant != 2 && !aligned)
-        variant = 2; // shapes the vector kernels cannot address fall to the direct kernel
-    // the wide kernel takes whole super-tiles only; every other shape runs the super-tile kernel (identical arithmetic)
-    if (variant == 1 && (a.channels % 64 != 0 || (a.samples * sizeof(S)) % 512 != 0 || (a.stride + 128) * sizeof(S) >= (1ull << 32)))
-        variant = 0;
-    if (variant == 2) {
-        const uint64_t blocks = (a.channels + 255) / 256;
+    constexpr bool f32 = sizeof(typename P::S) == 4 && sizeof(typename P::R) == 4;
+    const uint64_t blocks = id == IIR_K_DIRECT ? (a.channels + 255) / 256 : (a.channels + 63) / 64;
+    if (blocks > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
+    switch (id) {
+    case IIR_K_DIRECT:
         hipLaunchKernelGGL((sdsp_iir_direct_kernel<P, KIND, M>), dim3((uint32_t)blocks), dim3(256), 0, stream, p);
-    } else if (variant == 0) {
-        const uint64_t blocks = (a.channels + 63) / 64;
-        if (blocks > 0x7fffffffull)
-            return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
-        const size_t lds = 64 * (128 + 16);
-        hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
-    } else if (variant == 1) {
-        const uint64_t blocks = (a.channels + 63) / 64;
-        if (blocks > 0x7fffffffull)
-            return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
-        const size_t lds = 64 * (256 + 16);
-        hipLaunchKernelGGL((sdsp_iir_wide_kernel<P, KIND, M, true>), dim3((uint32_t)blocks), dim3(64), lds, stream, p);
-    } else {
+        break;
+    case IIR_K_SUPERTILE:
+        hipLaunchKernelGGL((sdsp_iir_supertile_kernel<P, KIND, M, true, 4>), dim3((uint32_t)blocks), dim3(64), 64 * (128 + 16), stream, p);
+        break;
+    case IIR_K_WIDE:
+        hipLaunchKernelGGL((sdsp_iir_wide_kernel<P, KIND, M, true>), dim3((uint32_t)blocks), dim3(64), 64 * (256 + 16), stream, p);
+        break;
+    case IIR_K_LANDING:
+        if constexpr (f32 && M <= 4)
+            return launch_landing<P, KIND, M, false>(a, stream);
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "the landing-slot kernel is built for f32, m_t <= 4");
+    case IIR_K_RING_LAB:
+    case IIR_K_RING_COPY_LAB:
+    case IIR_K_LANDING_COPY_LAB:
+        if constexpr (f32 && M == 4 && KIND == SDSP_HIP_IIR_GENERIC) {
+            if (id == IIR_K_RING_LAB)
+                return launch_dma<P, KIND, M, 256, 2, true, false>(a, stream);
+            if (id == IIR_K_RING_COPY_LAB)
+                return launch_dma<P, KIND, M, 256, 2, true, true>(a, stream);
+            return launch_landing<P, KIND, M, true>(a, stream);
+        }
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "lab variants exist for f32 casc_2o_iir<4> only");
+    default:
         return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
     }
     hipError_t e = hipGetLastError();
@@ -916,13 +908,13 @@ template <typename P, int KIND, int M> int launch_direct(const iir_args &a, hipS
     return SDSP_HIP_OK;
 }
 
-template <typename P, int KIND> int launch_k(const iir_args &a, int variant, hipStream_t stream)
+template <typename P, int KIND> int launch_k(const iir_args &a, iir_kernel_id id, hipStream_t stream)
 {
     switch (a.sections) {
-    case 2: return launch_km<P, KIND, 2>(a, variant, stream);
-    case 4: return launch_km<P, KIND, 4>(a, variant, stream);
-    case 6: return launch_km<P, KIND, 6>(a, variant, stream);
-    case 8: return launch_km<P, KIND, 8>(a, variant, stream);
+    case 2: return launch_km<P, KIND, 2>(a, id, stream);
+    case 4: return launch_km<P, KIND, 4>(a, id, stream);
+    case 6: return launch_km<P, KIND, 6>(a, id, stream);
+    case 8: return launch_km<P, KIND, 8>(a, id, stream);
     case 10: return launch_direct<P, KIND, 10>(a, stream);
     case 12: return launch_direct<P, KIND, 12>(a, stream);
     case 14: return launch_direct<P, KIND, 14>(a, stream);
@@ -931,13 +923,13 @@ template <typename P, int KIND> int launch_k(const iir_args &a, int variant, hip
     }
 }
 
-template <typename P> int launch_r(const iir_args &a, int variant, hipStream_t stream)
+template <typename P> int launch_r(const iir_args &a, iir_kernel_id id, hipStream_t stream)
 {
     switch (a.kind) {
-    case SDSP_HIP_IIR_GENERIC: return launch_k<P, SDSP_HIP_IIR_GENERIC>(a, variant, stream);
-    case SDSP_HIP_IIR_LP: return launch_k<P, SDSP_HIP_IIR_LP>(a, variant, stream);
-    case SDSP_HIP_IIR_HP: return launch_k<P, SDSP_HIP_IIR_HP>(a, variant, stream);
-    case SDSP_HIP_IIR_BP: return launch_k<P, SDSP_HIP_IIR_BP>(a, variant, stream);
+    case SDSP_HIP_IIR_GENERIC: return launch_k<P, SDSP_HIP_IIR_GENERIC>(a, id, stream);
+    case SDSP_HIP_IIR_LP: return launch_k<P, SDSP_HIP_IIR_LP>(a, id, stream);
+    case SDSP_HIP_IIR_HP: return launch_k<P, SDSP_HIP_IIR_HP>(a, id, stream);
+    case SDSP_HIP_IIR_BP: return launch_k<P, SDSP_HIP_IIR_BP>(a, id, stream);
     default: return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kind");
     }
 }
@@ -1030,8 +1022,13 @@ int launch_iir(int precision, const iir_args &a, int variant, void *stream)
     if ((a.channels + 255) / 256 > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const iir_kernel_id id = iir_select(precision, a, variant);
+    if (id == IIR_K_BAD)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "unknown IIR kernel variant");
     if (precision == SDSP_HIP_F32_F64STATE)
-        return launch_r<prec_mix>(a, variant, s);
-    return precision == SDSP_HIP_F64 ? launch_r<prec_f64>(a, variant, s) : launch_r<prec_f32>(a, variant, s);
+        return launch_r<prec_mix>(a, id, s);
+    return precision == SDSP_HIP_F64 ? launch_r<prec_f64>(a, id, s) : launch_r<prec_f32>(a, id, s);
 }
+
+const char *iir_kernel_for(int precision, const iir_args &a, int variant) { return iir_kernel_name(iir_select(precision, a, variant)); }
 } // namespace sdsp_hip

@@ -130,9 +130,10 @@ struct fft_2pass_args {
     uint64_t count;
     float scale;
     int reverse;
+    double scale_d = 1.0; // f64
 };
-bool fft_2pass_supports(uint32_t n);
-int launch_fft_2pass_f32(const fft_2pass_args &a, void *stream);
+bool fft_2pass_supports(uint32_t n, int precision);
+int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream);
 
 // N = 2^16 .. 2^19, f32 (variant 1) and larger / f64: the two streaming passes around 16 x batch row transforms (fft_mid.hip)
 int launch_fft_mid_cols(int precision, const void *in, void *out, const void *tw, uint32_t n2, uint64_t batch, int reverse,
@@ -181,6 +182,8 @@ struct iir_args {
     double b1[SDSP_HIP_MAX_SECTIONS], b2[SDSP_HIP_MAX_SECTIONS];
 };
 int launch_iir(int precision, const iir_args &a, int variant, void *stream);
+// the kernel launch_iir would run for this shape and variant (iir.hip: iir_select -- the same function the launcher uses)
+const char *iir_kernel_for(int precision, const iir_args &a, int variant);
 int launch_iir_interleaved(int precision, const iir_args &a, int variant, void *stream);
 
 // FIR bank

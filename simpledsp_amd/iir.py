@@ -109,6 +109,16 @@ class casc_2o_iir:
     def reset(self):
         self._state = None
 
+    def kernel_name(self, data, samples: int | None = None, offset: int = 0) -> str:
+        """the kernel process(data, samples, offset) would launch (the library's own selection function)"""
+        self._ensure_plan()
+        stride = data.shape[1]
+        samples = stride - offset if samples is None else samples
+        buf = C.create_string_buffer(64)
+        L.check(self._lib.sdsp_hip_iir_plan_kernel(self._plan, data.data_ptr() + offset * data.element_size(), self.channels,
+                                                   samples, stride, buf, 64))
+        return buf.value.decode()
+
     @property
     def state(self):
         """(3*(m_t+1), channels): row 3*j+age = level j's value `age+1` samples ago."""

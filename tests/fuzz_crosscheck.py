@@ -99,7 +99,7 @@ for case in range(cases):
             args = (float(rng.uniform(8e3, 20e3) if mode == 0 else rng.uniform(500, 20e3)), 100e3)
             {1: lambda: bank.set_lp_coeff(*args), 2: lambda: bank.set_hp_coeff(*args), 3: lambda: bank.set_bp_coeff(*args, 1.3),
              4: lambda: bank.set_bs_coeff(*args, 1.3)}[ftype]()
-            bank.set_variant(int(rng.integers(0, 3)))
+            bank.set_variant(int(rng.integers(0, 4)))
             dt = np.float64 if f64 else np.float32
             x = rng.standard_normal((channels, samples + pad)).astype(dt)
             cut = int(rng.integers(0, samples + 1))

@@ -293,7 +293,8 @@ def test_three_pass_mid_sizes(sd, torch_cuda, oracle, n, radix, batch):
             assert rel_max_err(got, want) < TOL32, (n, radix, rev, variant, rel_max_err(got, want))
 
 
-@pytest.mark.parametrize("n,radix,batch", [(1 << 14, 2, 5), (1 << 14, 4, 3), (1 << 15, 2, 3), (1 << 16, 4, 2), (1 << 18, 2, 2)])
+@pytest.mark.parametrize("n,radix,batch", [(1 << 14, 2, 5), (1 << 14, 4, 3), (1 << 15, 2, 3), (1 << 16, 4, 2), (1 << 16, 2, 3), (1 << 17, 2, 2),
+                                           (1 << 18, 2, 2), (1 << 19, 2, 1), (1 << 20, 2, 2)])
 def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
     """The three-pass schedule in double (N = 2^14 .. 2^21): rows on the f64 register-pass family, nested from 2^18."""
     torch = torch_cuda
@@ -302,21 +303,28 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
         want = oracle.fft(x, radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=2)
-        if n == 1 << 14 and radix == 2:  # round 3: the registers-resident kernel in double is this size's default ...
-            assert plan.info.kernel.decode() == "sdsp_fft_big_f64_kernel" and plan.info.hbm_passes == 1
+        fast = None  # round 3: sizes whose default is no longer the three-pass schedule (it became their variant 1)
+        if n == 1 << 14 and radix == 2:
+            fast = ("sdsp_fft_big_f64_kernel", 1)  # the registers-resident kernel in double
+        elif n >= 1 << 16:
+            fast = ("sdsp_fft2p_cols+sdsp_fft2p_rows", 2)  # the two-pass kernels in double
+        if fast:
+            assert plan.info.kernel.decode() == fast[0] and plan.info.hbm_passes == fast[1]
             d0 = torch.from_numpy(x).cuda()
             plan.exec(d0)
             torch.cuda.synchronize()
-            assert rel_max_err(d0.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
-            plan.set_variant(1)  # ... and the three-pass schedule its variant 1
+            assert rel_max_err(d0.cpu().numpy(), want) < _tol64(n), (n, radix, rev, rel_max_err(d0.cpu().numpy(), want))
+            plan.set_variant(1)
         assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
-        # N = 2^18 = 16 x 16384: its rows are one pass since the registers-resident kernel in double serves them (were three)
-        assert plan.info.hbm_passes == (3 if n <= (1 << 18) and not (n == 1 << 18 and radix == 4) else 5)
+        # column step + the rows' own passes + untwist.  Rows of 1024 .. 16384 (radix 2) are one pass (N = 16384: the
+        # registers-resident kernel in double, were three), rows of 2^15 three, rows of 2^16 two (the two-pass kernels in double)
+        rows_passes = {1 << 14: 1, 1 << 15: 1, 1 << 16: 1, 1 << 17: 1, 1 << 18: 1 if radix == 2 else 3, 1 << 19: 3, 1 << 20: 2}[n]
+        assert plan.info.hbm_passes == 2 + rows_passes
         d = torch.from_numpy(x).cuda()
         plan.exec(d)
         torch.cuda.synchronize()
         assert rel_max_err(d.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
-        plan.set_variant(2 if (n == 1 << 14 and radix == 2) else 1)  # the general four-step through the coverage kernel
+        plan.set_variant(2 if fast else 1)  # the general four-step through the coverage kernel
         d2 = torch.from_numpy(x).cuda()
         plan.exec(d2)
         torch.cuda.synchronize()

@@ -213,7 +213,7 @@ def test_mixed_precision_random_input_and_variants(sd, torch_cuda, oracle):
 @pytest.mark.parametrize("precision", ["f32", "f64", "mixed"])
 def test_wide_supertile_kernel_is_bit_identical(sd, torch_cuda, precision):
     """variant 1 (csrc/iir.hip: sdsp_iir_wide_kernel -- 512 contiguous bytes of two channels per load / store instruction)
-    takes whole super-tiles only (channels a multiple of 64, 512-byte multiples of samples); same arithmetic as variant 0,
+    takes whole super-tiles only (channels a multiple of 64, 512-byte multiples of samples); same arithmetic as variant 3,
     so the same bits, also across calls (per-channel state) and for every kind."""
     torch = torch_cuda
     prec = {"f32": sd.F32, "f64": sd.F64, "mixed": sd.F32_F64STATE}[precision]
@@ -222,9 +222,10 @@ def test_wide_supertile_kernel_is_bit_identical(sd, torch_cuda, precision):
     for nm, ftype in KINDS.items():
         for kind in (sd.IIR_GENERIC, ftype):
             outs = []
-            for variant in (0, 1):
+            for variant in (3, 1):
                 bank = _bank(sd, 4, 192, prec, kind, ftype, 10e3, 100e3, 1.1, variant=variant)
                 d = torch.from_numpy(x.copy()).cuda()
+                assert bank.kernel_name(d, samples=512, offset=0) == ("sdsp_iir_wide_kernel" if variant == 1 else "sdsp_iir_supertile_kernel")
                 bank.process(d, samples=512, offset=0)    # whole super-tiles: the wide kernel runs
                 bank.process(d, samples=384, offset=512)  # f32: 1536 bytes, f64: 3072 bytes -- still whole super-tiles
                 bank.process(d, samples=128, offset=896)
@@ -232,6 +233,43 @@ def test_wide_supertile_kernel_is_bit_identical(sd, torch_cuda, precision):
                 outs.append((d.cpu().numpy(), bank.state.cpu().numpy()))
             assert np.array_equal(outs[0][0], outs[1][0]), (precision, nm, kind)
             assert np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_landing_slot_kernel_is_bit_identical(sd, torch_cuda, m):
+    """round 3: the default kernel of f32 banks with m_t <= 4 on whole [64 channels x 512 bytes] tiles is the landing-slot
+    kernel (csrc/iir.hip: sdsp_iir_landing_kernel -- tile t + 1 arrives by LDS-DMA while tile t is filtered); same
+    cascade_step, so the same bits as the super-tile kernel (variant 3), for every kind, across calls (per-channel state),
+    and other shapes fall back to the super-tile / direct kernels inside the same call sequence."""
+    torch = torch_cuda
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((192, 2048)).astype(np.float32)
+    for nm, ftype in KINDS.items():
+        for kind in (sd.IIR_GENERIC, ftype):
+            outs = []
+            for variant in (0, 3):
+                bank = _bank(sd, m, 192, sd.F32, kind, ftype, 10e3, 100e3, 1.1, variant=variant)
+                d = torch.from_numpy(x.copy()).cuda()
+                want_k = "sdsp_iir_landing_kernel" if variant == 0 else "sdsp_iir_supertile_kernel"
+                assert bank.kernel_name(d, samples=1024, offset=0) == want_k
+                assert bank.kernel_name(d, samples=100, offset=1536) == "sdsp_iir_direct_kernel"  # 400 bytes: not 16-byte blocks
+                assert bank.kernel_name(d, samples=96, offset=1664) == "sdsp_iir_supertile_kernel"  # aligned, not whole tiles
+                bank.process(d, samples=1024, offset=0)   # eight whole tiles
+                bank.process(d, samples=128, offset=1024)  # one whole tile
+                bank.process(d, samples=384, offset=1152)  # three
+                bank.process(d, samples=100, offset=1536)  # direct kernel
+                bank.process(d, samples=28, offset=1636)
+                bank.process(d, samples=96, offset=1664)   # super-tile kernel, ragged tile
+                bank.process(d, samples=288, offset=1760)
+                torch.cuda.synchronize()
+                outs.append((d.cpu().numpy(), bank.state.cpu().numpy()))
+            assert np.array_equal(outs[0][0], outs[1][0]), (m, nm, kind)
+            assert np.array_equal(outs[0][1], outs[1][1])
+    # other precisions and deeper cascades keep the super-tile kernel as their default
+    for prec, mm in ((sd.F64, 4), (sd.F32_F64STATE, 4), (sd.F32, 6)):
+        bank = _bank(sd, mm, 192, prec, sd.IIR_GENERIC, 1, 10e3, 100e3, 1.1)
+        d = torch.zeros((192, 1024), dtype=torch.float64 if prec == sd.F64 else torch.float32, device="cuda")
+        assert bank.kernel_name(d) == "sdsp_iir_supertile_kernel"
 
 
 def test_f32_specialised_kinds_and_streaming(sd, torch_cuda, oracle):
