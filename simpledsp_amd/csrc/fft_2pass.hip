@@ -296,18 +296,275 @@ template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_a
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
+
+// ================================================================================================================
+// Round 3: a factor of 2048 -- N = 2^21 = 1024 x 2048 and N = 2^22 = 2048 x 2048 in TWO passes (were four / five nested ones).
+// A 2048-point sequence does not fit "32 points per thread, two register passes" (eleven stages); it is held by 32 threads
+// with SIXTY-FOUR points each: one top stage (span 1024) pairs register k with register k + 32 and owes the lower output
+// W_2048^(u + 32 k) = the thread's W_2048^u x the literal W_64^k; the two halves are then 1024-point sequences in exactly the
+// T = 32 layout of the kernels above (fft32_dif with thread twiddles W_1024^(u << s)); ONE exchange regroups to 64
+// consecutive positions per thread, and two constants-only fft32_dif finish.  128 data VGPRs, 512-thread workgroups (16
+// sequences), a 128 KiB plane: one workgroup per CU.  Index arithmetic replayed in numpy first: tools/model_fft2pass.py (run64).
+__device__ constexpr float kC64[32] = { 1.00000000000000000000f, 0.99518472667219692873f, 0.98078528040323043058f, 0.95694033573220882438f, 0.92387953251128673848f, 0.88192126434835504956f, 0.83146961230254523567f, 0.77301045336273699338f, 0.70710678118654757274f, 0.63439328416364548779f, 0.55557023301960228867f, 0.47139673682599780857f, 0.38268343236508983729f, 0.29028467725446233105f, 0.19509032201612833135f, 0.09801714032956077016f, 0.00000000000000006123f, -0.09801714032956064526f, -0.19509032201612819257f, -0.29028467725446216452f, -0.38268343236508972627f, -0.47139673682599769755f, -0.55557023301960195560f, -0.63439328416364537677f, -0.70710678118654746172f, -0.77301045336273699338f, -0.83146961230254534669f, -0.88192126434835493853f, -0.92387953251128673848f, -0.95694033573220882438f, -0.98078528040323043058f, -0.99518472667219681771f };
+__device__ constexpr float kS64[32] = { 0.00000000000000000000f, 0.09801714032956060363f, 0.19509032201612824808f, 0.29028467725446233105f, 0.38268343236508978178f, 0.47139673682599764204f, 0.55557023301960217765f, 0.63439328416364548779f, 0.70710678118654746172f, 0.77301045336273699338f, 0.83146961230254523567f, 0.88192126434835493853f, 0.92387953251128673848f, 0.95694033573220893540f, 0.98078528040323043058f, 0.99518472667219681771f, 1.00000000000000000000f, 0.99518472667219692873f, 0.98078528040323043058f, 0.95694033573220893540f, 0.92387953251128673848f, 0.88192126434835504956f, 0.83146961230254545772f, 0.77301045336273710440f, 0.70710678118654757274f, 0.63439328416364548779f, 0.55557023301960217765f, 0.47139673682599786408f, 0.38268343236508989280f, 0.29028467725446238656f, 0.19509032201612860891f, 0.09801714032956082567f };
+constexpr float kC2048 = 0.99999529380957617151f, kS2048 = 0.00306795676296597627f; // cos / sin of 2 pi / 2048
+
+// W_2048^u from the table W_1024^j (direction-folded): W_1024^(u >> 1), times W_2048^1 for odd u
+template <bool REV> __device__ __forceinline__ float2 w2048(const float2 *w1k, uint32_t u)
+{
+    const float2 w = w1k[u >> 1];
+    const float2 odd = cmul(w, float2{ kC2048, REV ? kS2048 : -kS2048 });
+    return (u & 1u) ? odd : w;
+}
+
+template <bool REV> __device__ __forceinline__ void top_stage64(float2 (&lo)[32], float2 (&hi)[32], float2 wu)
+{
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const float2 a = lo[k], b = hi[k];
+        lo[k] = a + b;
+        float2 d = a - b;
+        if (k == 16) {
+            d = REV ? float2{ -d.y, d.x } : float2{ d.y, -d.x };
+        } else if (k != 0) {
+            const float cr = kC64[k], ci = REV ? kS64[k] : -kS64[k];
+            d = float2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
+        }
+        hi[k] = cmul(d, wu);
+    }
+}
+
+// ---- pass 1 with N1 = 2048: 16 columns, 512 threads.  LDS: plane 2048 x 16 floats (slot = (row * 16 + col) ^ (((row >> 6) & 1) << 4)),
+// w1k = W_1024 (8 KiB), qtab 64 x 16 float2 (8 KiB)
+template <int L, bool REV>
+__device__ __forceinline__ void cols64_tile2p(const float2 *in_x, float2 *ws_x, uint32_t tile, float *plane, const float2 *w1k, float2 *qtab)
+{
+    constexpr int L1 = 11, L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
+    const uint32_t t = threadIdx.x;
+    const uint32_t c = t & 15, u = t >> 4; // u < 32
+    const uint32_t n2 = tile * kTile + c;
+
+    const float2 *src_tile = in_x + tile * kTile;
+    const uint32_t toff = (u * N2 + c) * 8u;
+    float2 lo[32], hi[32]; // rows u + 32 k and 1024 + u + 32 k
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        lo[k] = nt_load(at(src_tile + (size_t)32 * N2 * k, toff));
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        hi[k] = nt_load(at(src_tile + (size_t)32 * N2 * (k + 32), toff));
+    __syncthreads(); // w1k staged
+
+    // the column part of the inter-pass twiddle: W_N^(n2 * jj * 32), jj < 64; two entries per thread
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t jj = u + 32 * i;
+        qtab[jj * 16 + c] = twiddle_n<L, REV>(w1k, (n2 * jj) << 5);
+    }
+    top_stage64<REV>(lo, hi, w2048<REV>(w1k, u));
+    fft32_dif<REV, true>(lo, w1k, u);
+    fft32_dif<REV, true>(hi, w1k, u);
+
+    // exchange rows {1024 h + u + 32 k} -> {64 u + j}
+    {
+        float *const w0 = plane + (u * 16 + c);
+        float *const w1 = plane + ((u * 16 + c) ^ 16);
+        const int flip = (int)(u & 1) * 16;
+        const float *const r_even = plane + (1024 * u + c) + flip;
+        const float *const r_odd = plane + (1024 * u + c) - flip;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) { // bit 6 of the row = bit 1 of k
+                (((k >> 1) & 1) ? w1 : w0)[512 * k] = half ? lo[k].y : lo[k].x;
+                (((k >> 1) & 1) ? w1 : w0)[512 * k + 16384] = half ? hi[k].y : hi[k].x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const float f = ((j & 1) ? r_odd : r_even)[16 * j];
+                const float g = ((j & 1) ? r_odd : r_even)[16 * (j + 32)];
+                if (half) {
+                    lo[j].y = f;
+                    hi[j].y = g;
+                } else {
+                    lo[j].x = f;
+                    hi[j].x = g;
+                }
+            }
+            if (half == 0)
+                __syncthreads();
+        }
+    }
+    fft32_dif<REV, false, 0>(lo, w1k, 0);
+    fft32_dif<REV, false, 0>(hi, w1k, 0);
+
+    // row 64 u + j holds Y[k1], k1 = bit_reverse11(64 u + j) = 32 * jj + bit_reverse5(u), jj = (bit_reverse5(j & 31) << 1) | (j >> 5)
+    const uint32_t bu = brev_bits<5>(u);
+    const float2 pw = twiddle_n<L, REV>(w1k, n2 * bu);
+    const float2 *const qcol = qtab + c;
+    float2 *dst_tile = ws_x + (size_t)tile * (N1 * kTile); // [tile][k1][c]
+    const uint32_t soff = (bu * 16 + c) * 8u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if ((j & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        const int jj = (int)(__brev((uint32_t)j) >> 27) << 1;
+        *at(dst_tile + (size_t)jj * 512, soff) = cmul(lo[j], cmul(pw, qcol[16 * jj]));
+        *at(dst_tile + (size_t)(jj + 1) * 512, soff) = cmul(hi[j], cmul(pw, qcol[16 * (jj + 1)]));
+    }
+}
+template <int L, bool REV>
+__global__ __launch_bounds__(512) void sdsp_fft2p_cols64(const float2 *__restrict__ in, float2 *__restrict__ ws, const float2 *__restrict__ tw_1024)
+{
+    constexpr int N1 = 2048, N2 = 1 << (L - 11), TILES = N2 / kTile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
+    float2 *w1k = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(float));
+    stage_w1k2p(w1k, tw_1024, 512);
+    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+    cols64_tile2p<L, REV>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024);
+}
+
+// ---- pass 2 with N2 = 2048: 16 rows, written transposed; 512 threads.  LDS: plane 16 x 2048 floats
+// (slot(row, pos) = row * 2048 + (pos ^ (row | (((pos >> 6) & 1) << 4)))), wrow = [stage < 5][lane] W_1024^(lane << stage), [5][lane] W_2048^lane
+template <int L, int L1, bool REV>
+__device__ __forceinline__ void rows64_tile2p(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *wrow, float scale)
+{
+    constexpr int N1 = 1 << L1, N2 = 2048;
+    static_assert(L - L1 == 11, "rows of 2048");
+    const uint32_t t = threadIdx.x;
+    const uint32_t ra = t >> 5, ua = t & 31;
+    const float2 *src = ws_x + (size_t)tile * (kTile * kTile);
+    // element n2 = ua + 32 k of row k1 = 16 tile + ra lives at [(n2 >> 4)][k1][n2 & 15] of the intermediate
+    const uint32_t aoff = ((ua >> 4) * (N1 * kTile) + ra * 16 + (ua & 15)) * 8u;
+    float2 lo[32], hi[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        lo[k] = *at(src + (size_t)2 * k * (N1 * kTile), aoff);
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        hi[k] = *at(src + (size_t)2 * (k + 32) * (N1 * kTile), aoff);
+    __syncthreads(); // wrow staged
+    top_stage64<REV>(lo, hi, wrow[5 * 32 + ua]);
+    fft32_dif<REV, true, 0, true>(lo, wrow + ua, 32);
+    fft32_dif<REV, true, 0, true>(hi, wrow + ua, 32);
+
+    // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows: write pos = 1024 h + ua + 32 k of row
+    // ra; read pos = 64 ub + j of row rb
+    const uint32_t rb = t & 15, ub = t >> 4; // ub < 32
+    {
+        float *const wb0 = plane + ra * N2 + (ua ^ ra);
+        float *const wb1 = plane + ra * N2 + (ua ^ ra ^ 16);
+        const float *const r_base = plane + rb * N2 + 64 * ub;
+        const uint32_t rx = rb | ((ub & 1) << 4);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) { // bit 6 of pos = bit 1 of k
+                (((k >> 1) & 1) ? wb1 : wb0)[32 * k] = half ? lo[k].y : lo[k].x;
+                (((k >> 1) & 1) ? wb1 : wb0)[32 * k + 1024] = half ? hi[k].y : hi[k].x;
+            }
+            __syncthreads();
+            {
+                uint32_t q = rx;
+                asm volatile("" : "+v"(q)); // the 64 XOR'ed addresses are rebuilt, not kept in registers
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const float f = r_base[j ^ q];
+                    const float g = r_base[(j + 32) ^ q];
+                    if (half) {
+                        lo[j].y = f;
+                        hi[j].y = g;
+                    } else {
+                        lo[j].x = f;
+                        hi[j].x = g;
+                    }
+                }
+            }
+            if (half == 0)
+                __syncthreads();
+        }
+    }
+    fft32_dif<REV, false, 0>(lo, wrow, 0);
+    fft32_dif<REV, false, 0>(hi, wrow, 0);
+
+    // position 64 ub + j of row k1 holds X[k1 + N1 k2], k2 = (bit_reverse5(j & 31) << 6) | ((j >> 5) << 5) | bit_reverse5(ub): 16 lanes
+    // write 128 contiguous bytes (streaming store of the final result)
+    float2 *dst_tile = out_x + tile * kTile;
+    const uint32_t bub = brev_bits<5>(ub);
+    const uint32_t boff = (bub * N1 + rb) * 8u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if ((j & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0);
+        float2 v = lo[j], w = hi[j];
+        if constexpr (REV) { // reverse_fft::ScaleValues, fft.h:128-132
+            v.x *= scale;
+            v.y *= scale;
+            w.x *= scale;
+            w.y *= scale;
+        }
+        const size_t k2hi = (size_t)(__brev((uint32_t)j) >> 27) * 64;
+        nt_store(at(dst_tile + k2hi * N1, boff), v);
+        nt_store(at(dst_tile + (k2hi + 32) * N1, boff), w);
+    }
+}
+template <int L, int L1, bool REV>
+__global__ __launch_bounds__(512) void sdsp_fft2p_rows64(const float2 *__restrict__ ws, float2 *__restrict__ out, const float2 *__restrict__ tw_1024,
+                                                        float scale)
+{
+    constexpr int N1 = 1 << L1, N2 = 2048, TILES = N1 / kTile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    float *plane = reinterpret_cast<float *>(sdsp_fft2p_smem);
+    float2 *wrow = reinterpret_cast<float2 *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(float));
+    for (uint32_t i = threadIdx.x; i < 6 * 32; i += 512) // [stage][lane] = W_1024^(lane << stage); [5][lane] = W_2048^lane
+        wrow[i] = i < 5 * 32 ? tw_1024[(i & 31u) << (i >> 5)] : w2048<REV>(tw_1024, i & 31u);
+    const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
+    rows64_tile2p<L, L1, REV>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
+}
+
+// N = 2^21: the 32-point column pass above (N1 = 1024) + rows of 2048; N = 2^22: both passes of 2048
+template <int L, bool REV> int launch_pair64(const fft_2pass_args &a, hipStream_t s)
+{
+    constexpr int L1 = L == 21 ? 10 : 11, N1 = 1 << L1, N2 = 2048;
+    constexpr size_t lds_cols = L1 == 10 ? (size_t)N1 * kTile * 4 + 1024 * 8 + 32 * kTile * 8 : (size_t)2048 * kTile * 4 + 1024 * 8 + 64 * kTile * 8;
+    constexpr size_t lds_rows = (size_t)N2 * kTile * 4 + 6 * 32 * 8;
+    static std::atomic<uint64_t> done_c{ 0 }, done_r{ 0 };
+    const void *kc = L1 == 10 ? reinterpret_cast<const void *>(sdsp_fft2p_cols<L, 10, REV, float2>) : reinterpret_cast<const void *>(sdsp_fft2p_cols64<22, REV>);
+    if (int rc = ensure_dynamic_lds(kc, lds_cols, done_c))
+        return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows64<L, L1, REV>), lds_rows, done_r))
+        return rc;
+    const uint64_t blocks_c = a.count * (N2 / kTile), blocks_r = a.count * (N1 / kTile);
+    if (blocks_c > 0x7fffffffull || blocks_r > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
+    float2 *d = reinterpret_cast<float2 *>(a.data), *ws = reinterpret_cast<float2 *>(a.workspace);
+    const float2 *tw = reinterpret_cast<const float2 *>(a.tw_1024);
+    if constexpr (L1 == 10)
+        hipLaunchKernelGGL((sdsp_fft2p_cols<L, 10, REV, float2>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
+    else
+        hipLaunchKernelGGL((sdsp_fft2p_cols64<22, REV>), dim3((uint32_t)blocks_c), dim3(512), lds_cols, s, d, ws, tw);
+    hipLaunchKernelGGL((sdsp_fft2p_rows64<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(512), lds_rows, s, ws, d, tw, a.scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 template <int L, int L1, typename C> int launch_dir(const fft_2pass_args &a, hipStream_t s)
 {
     return a.reverse ? launch_pair<L, L1, true, C>(a, s) : launch_pair<L, L1, false, C>(a, s);
 }
 } // namespace
 
-// f32: N = 2^16 .. 2^19 (2^20 has the persistent kernel of fft1m.hip); f64: N = 2^16 .. 2^20
+// f32: N = 2^16 .. 2^19 and 2^21, 2^22 (2^20 has the persistent kernel of fft1m.hip); f64: N = 2^16 .. 2^20
 bool fft_2pass_supports(uint32_t n, int precision)
 {
     if (!sdsp_hip_is_power_of_2(n) || n < (1u << 16))
         return false;
-    return n <= (precision == SDSP_HIP_F64 ? (1u << 20) : (1u << 19));
+    if (precision == SDSP_HIP_F64)
+        return n <= (1u << 20);
+    return n <= (1u << 19) || n == (1u << 21) || n == (1u << 22);
 }
 
 // both passes over one chunk of `count` transforms (the workspace holds `count` intermediates)
@@ -333,6 +590,8 @@ int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream)
     case 1u << 17: return launch_dir<17, 8, float2>(a, s);  //  256 x  512
     case 1u << 18: return launch_dir<18, 9, float2>(a, s);  //  512 x  512
     case 1u << 19: return launch_dir<19, 9, float2>(a, s);  //  512 x 1024
+    case 1u << 21: return a.reverse ? launch_pair64<21, true>(a, s) : launch_pair64<21, false>(a, s); // 1024 x 2048
+    case 1u << 22: return a.reverse ? launch_pair64<22, true>(a, s) : launch_pair64<22, false>(a, s); // 2048 x 2048
     default: break;
     }
     return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");

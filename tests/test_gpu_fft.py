@@ -265,20 +265,23 @@ def test_fft4096_ragged_batches_all_variants(sd, torch_cuda, oracle, batch):
 
 
 @pytest.mark.parametrize("n,radix,batch", [(1 << 16, 2, 5), (1 << 16, 4, 3), (1 << 17, 2, 3), (1 << 18, 4, 2), (1 << 19, 2, 2),
-                                           (1 << 21, 2, 2), (1 << 22, 4, 1)])  # > 2^20: nested (the rows are three-pass plans)
+                                           (1 << 21, 2, 3), (1 << 22, 4, 1), (1 << 22, 2, 3), (1 << 23, 2, 1)])
 def test_three_pass_mid_sizes(sd, torch_cuda, oracle, n, radix, batch):
-    """N = 2^16 .. 2^19, f32: two passes over HBM (csrc/fft_2pass.hip, N = N1 x N2 with N1, N2 in {256, 512, 1024});
+    """N = 2^16 .. 2^19, f32: two passes over HBM (csrc/fft_2pass.hip, N = N1 x N2 with N1, N2 in {256, 512, 1024}); round 3:
+    N = 2^21 = 1024 x 2048 and N = 2^22 = 2048 x 2048 too (a factor of 2048 = 32 threads x 64 points; were four nested passes);
     variant 1: the three streaming passes of csrc/fft_mid.hip (16-point column step, 16 x batch rows on the tuned
-    single-pass kernels, untwist) -- which N = 2^21 .. 2^23 still run, nested; last variant: the general four-step
+    single-pass kernels, untwist) -- which N = 2^23 still runs, nested; last variant: the general four-step
     through the coverage kernel.  All against the oracle, with a plan whose workspace is smaller than the batch (slices)."""
     torch = torch_cuda
     rng = np.random.default_rng(n + radix + batch)
     x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
-    two_pass = n < (1 << 20)
+    two_pass = n != (1 << 23)
+    mid_passes = 3 if n < (1 << 20) else 4  # column step + the rows' passes (one; two for rows of 2^17 .. 2^19) + untwist
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
-        want = oracle.fft(x.astype(np.complex128), radix, rev)
+        want = oracle.fft(x.astype(np.complex128), radix, rev) if n <= (1 << 20) else \
+            (np.fft.ifft(x.astype(np.complex128), axis=-1) if rev else np.fft.fft(x.astype(np.complex128), axis=-1))
         plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=2)  # batch > max_batch: the exec runs in slices
-        expect = [("sdsp_fft2p_cols", 2), ("sdsp_fft_col16_kernel", 3), ("sdsp_fft_tile_kernel", 2)] if two_pass else \
+        expect = [("sdsp_fft2p_cols", 2), ("sdsp_fft_col16_kernel", mid_passes), ("sdsp_fft_tile_kernel", 2)] if two_pass else \
                  [("sdsp_fft_col16_kernel", 4), ("sdsp_fft_tile_kernel", 2)]  # nested: column step + two-pass rows + untwist
         for variant, (kernel, passes) in enumerate(expect):
             plan.set_variant(variant)

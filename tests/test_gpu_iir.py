@@ -252,13 +252,13 @@ def test_landing_slot_kernel_is_bit_identical(sd, torch_cuda, m):
                 d = torch.from_numpy(x.copy()).cuda()
                 want_k = "sdsp_iir_landing_kernel" if variant == 0 else "sdsp_iir_supertile_kernel"
                 assert bank.kernel_name(d, samples=1024, offset=0) == want_k
-                assert bank.kernel_name(d, samples=100, offset=1536) == "sdsp_iir_direct_kernel"  # 400 bytes: not 16-byte blocks
+                assert bank.kernel_name(d, samples=98, offset=1536) == "sdsp_iir_direct_kernel"  # 392 bytes: not 16-byte blocks
                 assert bank.kernel_name(d, samples=96, offset=1664) == "sdsp_iir_supertile_kernel"  # aligned, not whole tiles
                 bank.process(d, samples=1024, offset=0)   # eight whole tiles
                 bank.process(d, samples=128, offset=1024)  # one whole tile
                 bank.process(d, samples=384, offset=1152)  # three
-                bank.process(d, samples=100, offset=1536)  # direct kernel
-                bank.process(d, samples=28, offset=1636)
+                bank.process(d, samples=98, offset=1536)  # direct kernel
+                bank.process(d, samples=30, offset=1634)  # direct kernel (the block starts off a 16-byte boundary)
                 bank.process(d, samples=96, offset=1664)   # super-tile kernel, ragged tile
                 bank.process(d, samples=288, offset=1760)
                 torch.cuda.synchronize()

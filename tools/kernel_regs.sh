@@ -1,5 +1,8 @@
 #!/bin/bash
-# Register / scratch / LDS use of every kernel in one csrc file:  tools/kernel_regs.sh fft_big.hip [extra hipcc flags]
+# Register / scratch / STATIC LDS use of every kernel in one csrc file, from the compiler's .amdhsa metadata:
+#   tools/kernel_regs.sh fft_big.hip [extra hipcc flags]
+# (vgpr = .amdhsa_next_free_vgpr: architectural VGPRs incl. the AGPR block above accum_off; "lds" is the static segment only -- the
+# kernels here take dynamic LDS, sized by their launchers: DESIGN.md section 5)
 src=$1; shift
 tmp=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Isimpledsp_amd/csrc -fno-slp-vectorize "$@" \

@@ -61,10 +61,9 @@ if trace:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in t]
     lines += ["launch-by-launch durations of the sdsp kernels (us), in order:", "",
               " ".join(f"{d:.0f}" for d in durs), ""]
-    if t:
-        r = t[0]
-        lines += [f"resources: VGPR {r.get('VGPR_Count')}, SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, "
-                  f"scratch {r.get('Scratch_Size')} B, workgroup {r.get('Workgroup_Size')}, grid {r.get('Grid_Size')}", ""]
+    # (no resource line here: rocprofv3's VGPR_Count / LDS_Block_Size columns report allocation granules and static LDS only --
+    # round 2's summaries said "VGPR 104, LDS 0 B" for a 203-VGPR kernel launched with 9 KiB of dynamic LDS.  The compiler's own
+    # figures per kernel are in profiles/r03_kernel_regs.txt (tools/kernel_regs.sh); dynamic LDS sizes are in DESIGN.md section 5.)
 
 traffic = {}
 pm = defaultdict(lambda: defaultdict(list))
