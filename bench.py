@@ -418,7 +418,7 @@ def measure(name, sd, torch, dev, args, dist, steps, warmup):
     # consecutive pieces (include/sdsp_hip.h: sdsp_hip_set_launch_piece_bytes); the library says how many
     # (sdsp_hip_fft_plan_launches), and for a single-kernel path the roofline is per launch: bytes and duration both divided
     launches = 1
-    if desc.get("hbm_passes") == 1 and hasattr(keep[0], "launches"):
+    if hasattr(keep[0], "launches"):  # multi-pass paths: launches of ALL their kernels (cols + rows per workspace slice ...)
         launches = max(1, keep[0].launches(units))
     kern_ms = step_ms / launches
     world = args.world

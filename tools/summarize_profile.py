@@ -82,12 +82,14 @@ for k, c in pm.items():
     b = (2 * f + wv) * 1024
     traffic[k] = {"hbm_bytes_per_launch": b, "fetch_size_kib_raw": f, "write_size_kib": wv, "profile": tag}
     lines.append(f"| `{k}` | {f:.1f} | {wv:.1f} | {b:.4g} |")
-# launches of each kernel per bench step: 1, except the chunked variant of the N=2^20 path (256 transforms per step
-# in chunks of 32 -> 8 launches of each pass, csrc/capi.hip)
-LAUNCHES_PER_STEP = {"sdsp_fft1m_cols": 8, "sdsp_fft1m_rows": 8}
+# launches of each kernel per bench step: the bench line's launches_per_step (sdsp_hip_fft_plan_launches: all kernels of the
+# path, every workspace slice / launch piece) spread evenly over the path's kernels ("a+b" in roofline.kernel)
+rf = bench.get("roofline", {})
+path_kernels = [k for k in rf.get("kernel", "").split("+") if k and k != "rows"]
+per_kernel = max(1, int(rf.get("launches_per_step", 1)) // max(1, len(path_kernels)))
 for k in traffic:
-    traffic[k]["launches_per_step"] = LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
-alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
+    traffic[k]["launches_per_step"] = per_kernel
+alg = rf.get("algorithmic_bytes_per_launch", 0) * rf.get("launches_per_step", 1)  # per STEP
 if alg:
     per_step = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in traffic.values())
     n_inst = max(1, len(traffic) // max(1, len({k.split("<")[0] for k in traffic})))  # fwd/rev instantiations
@@ -106,9 +108,12 @@ for k, vs in merged.items():
     allt[k] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in vs) / len(vs),
                # the profiled workload's algorithmic bytes per launch of this kernel: bench.py scales the measured
                # traffic / algorithmic ratio to the launch it reports (same kernel, other batch or sample type)
-               "algorithmic_bytes_per_launch": (alg / vs[0]["launches_per_step"]) if alg else None,
+               "algorithmic_bytes_per_launch": (alg / vs[0]["launches_per_step"]) if alg else None,  # each kernel of a path moves the step's bytes once
                "fetch_size_kib_raw": sum(v["fetch_size_kib_raw"] for v in vs) / len(vs),
                "write_size_kib": sum(v["write_size_kib"] for v in vs) / len(vs),
                "launches_per_step": vs[0]["launches_per_step"], "profile": tag}
+    n_cfg = bench.get("config", {}).get("n")
+    if n_cfg:  # the same kernel template serves several sizes: also keep the entry under "<kernel>@<n>" (bench.py prefers it)
+        allt[f"{k}@{n_cfg}"] = dict(allt[k])
 tj.write_text(json.dumps(allt, indent=1) + "\n")
 print((out / f"{tag}_summary.md").read_text())
