@@ -28,10 +28,10 @@ for case in range(cases):
     sd.set_launch_piece_bytes(int(rng.choice([default_piece, default_piece, 0, 1 << 20, 3 << 19, 5 << 20])))
     try:
         if kind in ("fft", "conv", "rfft"):
-            log2n = int(rng.integers(1, 22)) if kind == "fft" else int(rng.integers(4, 16))  # up to 2^21: nested three-pass plans
+            log2n = int(rng.integers(1, 23)) if kind == "fft" else int(rng.integers(4, 16))  # up to 2^22 (two-pass since round 3)
             n = 1 << log2n
             radix = 4 if (log2n % 2 == 0 and rng.random() < 0.5) else 2
-            f64 = kind == "fft" and rng.random() < 0.3 and n <= (1 << 18)
+            f64 = kind == "fft" and rng.random() < 0.3 and n <= (1 << 20)  # 2^16 .. 2^20: the two-pass kernels in double
             batch = int(rng.integers(1, max(3, min(300, (1 << 18) // n))))
             rev = bool(rng.integers(0, 2))
             cdt = np.complex128 if f64 else np.complex64
