@@ -421,7 +421,7 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
         // one-wave kernels (fft_wave.hip), where they measured faster than the register-pass family.  Complex transform:
         // N = 1024 (either stage type), N = 256 / 2048 radix 2 (N = 512: 72.1-72.8 % against 74.2-74.8 % there).  Real-input
         // plans (split / merge by ds_bpermute): n_real = 512 / 1024 / 2048 radix 2: 71.9 / 70.5 / 67.3 % against 70.6 / 66.5 /
-        // 66.2 % (radix 4 at 2048: 65.5 / 65.6; n_real = 4096: 59.8 against 64.5 %, 174 VGPRs -- both stay with the family)
+        // 66.2 % (radix 4 at 2048: 65.5 / 65.6: stays with the family; n_real = 4096 .. 65536 radix 2 were taken by K_BIG_REAL above)
         if (variant == 0 && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
             return { K_WAVE1024, "sdsp_fft1024_wave", 1, p->radix, false, pc };
         if (variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
@@ -1225,7 +1225,7 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
         a.tw2 = h;
         if (p->variant == 0 && fft_wave_supports(p->n, p->radix)) // N = 1024: both transforms in one wave's registers (fft_wave.hip)
             return launch_fft_wave_f32(a, stream);
-        if (p->variant == 0 && p->twt_wave) { // N = 256 / 512 / 2048 radix 2
+        if (p->variant == 0 && p->twt_wave) { // N = 256 / 512 radix 2 (N = 2048 radix 2 was taken by the fft_big.hip form above: 65-69 % against 52 %)
             a.tw = p->twt_wave;
             return launch_fft_wave2_f32(a, stream);
         }

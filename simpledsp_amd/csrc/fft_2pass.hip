@@ -186,7 +186,7 @@ __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t ti
     fft32_dif<REV, true, 0, true>(x, wrow + ua, 32);
 
     // exchange, and switch the thread mapping so that 16 lanes run across the 16 rows:
-    //   slot(row, pos) = row * N2 + (pos ^ (row | (((pos >> 5) & 1) << 4)))
+    //   slot(row, pos) = row * N2 + (pos ^ (mask(row) | (((pos >> 5) & 1) << 4))), mask(row) = row (rows of 256: row rotated right by one)
     // write pos = ua + T2 k of row ra; read pos = 32 ub + k of row rb
     const uint32_t rb = t & 15, ub = t >> 4; // ub < T2
     {
@@ -197,11 +197,16 @@ __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t ti
         } else if constexpr (T2 == 16) { // low 4 bits ua, bit 4 = k & 1, bit 5 = (k >> 1) & 1
             wb0 = wb1 = plane + ra * N2 + (ua ^ ra);
         } else { // low 3 bits ua, bit 3 = k & 1, bit 4 = (k >> 1) & 1, bit 5 = (k >> 2) & 1
-            wb0 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (ra >> 3);       // k even: bit 3 = 0 ^ (ra >> 3)
-            wb1 = plane + ra * N2 + (ua ^ (ra & 7)) + 8 * (1 - (ra >> 3)); // k odd:  bit 3 = 1 ^ (ra >> 3)
+            // rows of 256: a write instruction's lanes span 2 (b64) / 4 (b32) consecutive rows of 8 positions each, so the row's XOR
+            // mask is its index ROTATED (row >> 1 | (row & 1) << 3): rows 2m and 2m + 1 then differ in bit 3 and fill different
+            // halves of the 16 slots -- conflict-free ds_write_b64 (was 2-way: 38 % LDS conflict cycles in double,
+            // profiles/r03_lds_bank_conflicts.md), 2-way = free ds_write_b32 (was 4-way); the reads only need 16 distinct masks
+            wb0 = plane + ra * N2 + (ua ^ (ra >> 1)) + 8 * (ra & 1);       // k even: bit 3 = 0 ^ (ra & 1)
+            wb1 = plane + ra * N2 + (ua ^ (ra >> 1)) + 8 * (1 - (ra & 1)); // k odd:  bit 3 = 1 ^ (ra & 1)
         }
         const Real *const r_base = plane + rb * N2 + 32 * ub;
-        const uint32_t rx = rb | ((ub & 1) << 4);
+        const uint32_t rmask = T2 == 8 ? ((rb >> 1) | ((rb & 1) << 3)) : rb;
+        const uint32_t rx = rmask | ((ub & 1) << 4);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll

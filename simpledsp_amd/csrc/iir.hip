@@ -564,7 +564,10 @@ __global__ __launch_bounds__(64) void sdsp_iir_landing_kernel(iir_dev_args<typen
 
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_iir_smem[];
     unsigned char *const land = sdsp_iir_smem;
-    unsigned char *const xp = sdsp_iir_smem + TILE; // 64 rows x 128 bytes, chunk k of row r at position k ^ ((r >> 1) & 7)
+    // 64 rows x 128 bytes, chunk k of row r at position k ^ (r & 7): the row-per-lane ds_write_b128 (8 contiguous lanes per
+    // LDS cycle, 32 banks) then hits eight distinct 16-byte columns; the read-back is lane-linear.  (The first version used the ring
+    // kernel's 128-byte-row map (r >> 1) & 7, which is made for row-per-lane READS: 33 % LDS conflict cycles, r03_lds_bank_conflicts.md)
+    unsigned char *const xp = sdsp_iir_smem + TILE;
     const int lane = threadIdx.x;
     const uint64_t ch0 = (uint64_t)blockIdx.x * 64;
     const uint64_t my_ch = ch0 + lane;
@@ -591,8 +594,8 @@ __global__ __launch_bounds__(64) void sdsp_iir_landing_kernel(iir_dev_args<typen
     // output side: store instruction (i, j) covers rows 8 i .. 8 i + 7, piece j; this lane: row 8 i + sub, position pc
     const int sub = lane / PCH, pc = lane % PCH;
     const uint32_t out_row = (uint32_t)(sub * row_bytes);
-    auto out_off = [&](int i) { return out_row + 16u * (uint32_t)(pc ^ iir_dma_swz<PB>(8 * i + sub)); };
-    const int fo = iir_dma_swz<PB>(lane);
+    auto out_off = [&](int) { return out_row + 16u * (uint32_t)(pc ^ sub); }; // row 8 i + sub: (8 i + sub) & 7 = sub
+    const int fo = lane & 7;
 
     if (n_tiles)
         fill(0);

@@ -88,18 +88,19 @@ def run(L, L1, rev, rng):
             elif T2 == 16:
                 addr = ra * N2 + (ua ^ ra) + 16 * ((kk ^ (kk >> 1)) & 1) + 32 * (kk >> 1)
             else:
-                b0 = ra * N2 + (ua ^ (ra & 7)) + 8 * (ra >> 3)
-                b1 = ra * N2 + (ua ^ (ra & 7)) + 8 * (1 - (ra >> 3))
+                b0 = ra * N2 + (ua ^ (ra >> 1)) + 8 * (ra & 1)
+                b1 = ra * N2 + (ua ^ (ra >> 1)) + 8 * (1 - (ra & 1))
                 addr = np.where(kk & 1, b1, b0) + 16 * (((kk >> 1) ^ (kk >> 2)) & 1) + 32 * (kk >> 2)
-            # the kernel's formula must equal the defining swizzle of the slot
+            # the kernel's formula must equal the defining swizzle of the slot (rows of 256: the row's mask is its index rotated)
             pos = ua + T2 * kk
-            want = ra * N2 + (pos ^ (ra | (((pos >> 5) & 1) << 4)))
+            mask = ((ra >> 1) | ((ra & 1) << 3)) if T2 == 8 else ra
+            want = ra * N2 + (pos ^ (mask | (((pos >> 5) & 1) << 4)))
             assert (addr == want).all(), (L, L1, kk)
             assert np.isnan(plane[addr]).all()
             plane[addr] = reg[:, kk]
         assert not np.isnan(plane).any()
         rb, ub = t & 15, t >> 4
-        rx = rb | ((ub & 1) << 4)
+        rx = (((rb >> 1) | ((rb & 1) << 3)) if T2 == 8 else rb) | ((ub & 1) << 4)
         reg2 = np.empty_like(reg)
         for kk in range(32):
             reg2[:, kk] = plane[rb * N2 + 32 * ub + (kk ^ rx)]
