@@ -866,9 +866,13 @@ def test_bench_under_torch_distributed_run_on_one_gpu(sd, torch_cuda):
     import subprocess
     import sys
     from conftest import ROOT
+    import socket
+    with socket.socket() as sock:  # a port nobody holds right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, SDSP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29713", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-other-configs",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-other-configs",
            "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

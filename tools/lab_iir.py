@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """One-call A/B of the biquad bank's kernel variants on BASELINE configs[3] (1M channels x 4096 samples):
-    tools/lab_iir.py [f32|f64|mix] V0,V1,...  [channels]  [rounds]
+    tools/lab_iir.py [f32|f64|mix] V0,V1,...  [channels]  [rounds] [check]
+Variants (csrc/iir.hip: iir_select): 0 default (f32: landing slot), 1 wide super-tile, 2 direct, 3 super-tile; lab, f32 only:
+10 LDS-DMA ring, 19 landing slot without the recurrence, 20 ring without the recurrence.  (profiles/r03_iir_lab.md's tables were
+made with the lab numbering of the time: 18 = today's 0, 0 = today's 3, 9 / 11-17 / 21-29 = ring shapes no longer instantiated.)
 Every variant is first checked bit-for-bit against variant 0 on a small bank (the kernels share cascade_step, so any
 difference is an addressing bug), then all variants are timed interleaved in one process, `rounds` times (same-call
 numbers: the only ones that may be compared to a point)."""
