@@ -56,7 +56,8 @@ def hipcc() -> str:
 def source_hash() -> str:
     """sha256 over everything the library is built from: csrc/*, include/**, and this file's flags"""
     h = hashlib.sha256()
-    files = sorted(CSRC.glob("*")) + sorted((ROOT / "include").rglob("*.h")) + [Path(__file__)]
+    # (everything through the resolved package path: the tree may be reached through a symlink, as /root/repo is on the GPU box)
+    files = sorted(CSRC.glob("*")) + sorted((ROOT / "include").rglob("*.h")) + [Path(__file__).resolve()]
     for f in files:
         if f.is_file():
             h.update(f.relative_to(ROOT).as_posix().encode())
@@ -90,7 +91,7 @@ def object_stale(obj: Path, src: Path) -> bool:
     deps = _dep_files(obj.with_suffix(".d"))
     if deps is None:
         return True
-    return _stale(obj, [src, Path(__file__), *deps])
+    return _stale(obj, [src, Path(__file__).resolve(), *deps])
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:

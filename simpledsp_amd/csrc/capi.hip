@@ -200,14 +200,14 @@ int upload_thread_twiddles_big(const std::vector<double> &w, uint32_t n, int pre
 // For N = 16384: slots 0-2: W_N^(q t); 3-5: W_4096^(q t); 6, 7: stage 2's pair for the thread's block parity -- (1, W_1024^(2v)) for an
 // even block, (W_1024^v, W_1024^(3v)) for an odd one; 8-10: W_256^(q v); 11-13: W_64^(q v); q = 1, 2, 3, v = t mod 16, block = t / 16.
 // `w` is the row W_N^j, direction-folded.  tools/model_fft_big_r4.py is the index arithmetic's model.
-int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void **dev)
+int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, int precision, void **dev)
 {
     const uint32_t T = n / 32, R = sdsp_hip_log2(n) - 10; // R = 4 (N = 16384) or 2 (N = 4096); v = t mod 2^R, block = t >> R
-    std::vector<float> tab((size_t)14 * T * 2);
+    std::vector<double> tab((size_t)14 * T * 2);
     auto put = [&](uint32_t slot, uint32_t t, uint64_t idx) {
         idx %= n;
-        tab[((size_t)slot * T + t) * 2] = (float)w[2 * idx];
-        tab[((size_t)slot * T + t) * 2 + 1] = (float)w[2 * idx + 1];
+        tab[((size_t)slot * T + t) * 2] = w[2 * idx];
+        tab[((size_t)slot * T + t) * 2 + 1] = w[2 * idx + 1];
     };
     for (uint32_t t = 0; t < T; t++) {
         const uint32_t v = t & ((1u << R) - 1), odd = (t >> R) & 1;
@@ -220,9 +220,7 @@ int upload_thread_twiddles_big_r4(const std::vector<double> &w, uint32_t n, void
         put(6, t, odd ? (uint64_t)16 * v : 0);             // stage 2 (G = N/16), j < 16: q = 1 (odd block) / none
         put(7, t, (uint64_t)16 * (odd ? 3 : 2) * v);       // j >= 16: q = 3 (odd) / 2 (even)
     }
-    HIP_TRY(hipMalloc(dev, tab.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(*dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    return SDSP_HIP_OK;
+    return upload_twiddles(tab, precision, dev); // rounds to the plan precision exactly like the row itself
 }
 
 // N = 16384 radix-4 plans: fft_big.hip's radix-4 form is variant 0 and the fft_mix.hip kernel variant 1
@@ -401,13 +399,14 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
     // the register-pass family's MODE 1 / 2
     if (p->path == PATH_REG && f32 && variant == 0 && p->real_mode && p->twt_big && fft_big_real_supports(p->n, p->radix))
         return { K_BIG_REAL, "sdsp_fft_big_kernel", 1, big_r4_form(p->n, p->radix) ? 4 : 2, false, pc };
-    // double precision, radix-2 plans of N = 4096 / 8192 / 16384: the registers-resident kernel in double (fft_big64.hip).
+    // double precision, N = 4096 / 8192 / 16384: the registers-resident kernel in double (fft_big64.hip) -- radix-2 stages, or, for
+    // radix-4 plans of N = 4096 / 16384, genuine radix-4 stages (its R4 form).
     // The default of all three sizes: 73.4 / 74.5 / 59.5 % of HBM peak against 67.5 % (N = 4096, fft_reg64.hip), 51.4 % (N = 8192:
     // the whole tile in LDS) and 24.2 % (N = 16384: three streaming passes) in one call (tools/sweep_sizes64.py, round 3);
     // what served a size before is its variant 1
     const bool big64 = !f32 && !p->real_mode && p->twt_big && fft_big64_supports(p->n, p->radix);
     if (big64 && variant == big64_variant(p->n))
-        return { K_BIG64, "sdsp_fft_big_f64_kernel", 1, 2, false, pc && p->n <= 4096 };
+        return { K_BIG64, "sdsp_fft_big_f64_kernel", 1, p->radix == 4 ? 4 : 2, false, pc && p->n <= 4096 };
     if (p->path == PATH_REG && !f32) {
         if (big64 && big64_variant(p->n) == 0) // the kernel that was the default becomes variant 1
             variant = variant == 1 ? 0 : variant;
@@ -924,9 +923,9 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
                     (precision == SDSP_HIP_F64 && fft_reg64_supports(n, radix))))
             rc = upload_thread_twiddles_reg(w, n, radix, precision, &p->twt_reg);
         if (!rc && precision == SDSP_HIP_F32 && (fft_big_supports(n, radix) || fft_big_conv_supports(n, radix)))
-            rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big);
+            rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F32, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F64 && fft_big64_supports(n, radix))
-            rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
+            rc = radix == 4 ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F64, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F32 && fft_wave2_supports(n, radix))
             rc = upload_thread_twiddles_wave(w, n, radix, &p->twt_wave);
         if (!rc && precision == SDSP_HIP_F32 && fft_mix_supports(n) && p->allow_mix)
@@ -952,7 +951,7 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc && precision == SDSP_HIP_F32 && fft_big_supports(n, radix))
             rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big);
         if (!rc && precision == SDSP_HIP_F64 && fft_big64_supports(n, radix))
-            rc = upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
+            rc = radix == 4 ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F64, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F64, &p->twt_big);
         if (!rc) {
             make_twiddles(p->n1, direction, w);
             rc = upload_twiddles(w, precision, &p->tw1);
@@ -1029,7 +1028,7 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
     std::vector<double> w;
     if (big_real && !p->twt_big) { // (every complex plan this kernel serves has the table already)
         make_twiddles(n, direction, w);
-        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big)) {
+        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F32, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big)) {
             sdsp_hip_fft_plan_destroy(p);
             return rc;
         }

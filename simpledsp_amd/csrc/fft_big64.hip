@@ -22,101 +22,37 @@
 // conflict-free (tools/model_fft_big_lds.py checks the forms below against sw<L> for every thread and register).
 // Thread twiddles: the plan's [pass][stage][thread] table in double (capi.hip: upload_thread_twiddles_big, precision f64),
 // combined with compile-time W_32 constants.  Parity: the reference's own bound 4 N eps against the oracle.
+// R4: radix-4 plans (sdsp::fft_radix4, fft.h:301-360 -- the reference's own precision and stage type) of N = 4096 = 4^6 and
+// N = 16384 = 4^7 run genuine radix-4 DIF stages in the same kernel: fft32_r4.h's layers on double2, arranged exactly as in
+// fft_big.hip's R4 form (two stages and half of the third in pass A, ...), on the plan's radix-4 thread-twiddle table in double.
 #include <hip/hip_runtime.h>
 
+#include "fft32.h"
+#include "fft32_r4.h"
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
 {
 namespace
 {
-typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+using namespace fft32; // operator+/-, cmul, fft32_dif and the radix-4 layers, generic over float2 / double2
 
 // rows of one transform through a buffer resource (fft32.h: make_rows): the row's byte offset in an SGPR next to ONE VGPR
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rows(const double2 *base, uint32_t bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rows64(const double2 *base, uint32_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(base), 0, (int)bytes, 0x00020000);
 }
-template <bool NT> __device__ __forceinline__ double2 row_load(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off)
+template <bool NT> __device__ __forceinline__ double2 row_load64(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off)
 {
     const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rows, thread_off, row_off, NT ? 2 : 0);
     const unsigned int a = v.x, b = v.y, c = v.z, d = v.w;
     return double2{ __hiloint2double((int)b, (int)a), __hiloint2double((int)d, (int)c) };
 }
-template <bool NT> __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off, double2 a)
+template <bool NT> __device__ __forceinline__ void row_store64(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off, double2 a)
 {
     const v4u_t v = { (unsigned)__double2loint(a.x), (unsigned)__double2hiint(a.x), (unsigned)__double2loint(a.y),
                       (unsigned)__double2hiint(a.y) };
     __builtin_amdgcn_raw_buffer_store_b128(v, rows, thread_off, row_off, NT ? 2 : 0);
-}
-__device__ __forceinline__ double2 add2(double2 a, double2 b) { return double2{ a.x + b.x, a.y + b.y }; }
-__device__ __forceinline__ double2 sub2(double2 a, double2 b) { return double2{ a.x - b.x, a.y - b.y }; }
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return double2{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
-
-// cos / sin of 2*pi*j/32, j < 16 (correctly rounded doubles)
-__device__ constexpr double kC32d[16] = { 1.0,
-                                          0.98078528040323044913,
-                                          0.92387953251128675613,
-                                          0.83146961230254523708,
-                                          0.70710678118654752440,
-                                          0.55557023301960222474,
-                                          0.38268343236508977173,
-                                          0.19509032201612826785,
-                                          0.0,
-                                          -0.19509032201612826785,
-                                          -0.38268343236508977173,
-                                          -0.55557023301960222474,
-                                          -0.70710678118654752440,
-                                          -0.83146961230254523708,
-                                          -0.92387953251128675613,
-                                          -0.98078528040323044913 };
-__device__ constexpr double kS32d[16] = { 0.0,
-                                          0.19509032201612826785,
-                                          0.38268343236508977173,
-                                          0.55557023301960222474,
-                                          0.70710678118654752440,
-                                          0.83146961230254523708,
-                                          0.92387953251128675613,
-                                          0.98078528040323044913,
-                                          1.0,
-                                          0.98078528040323044913,
-                                          0.92387953251128675613,
-                                          0.83146961230254523708,
-                                          0.70710678118654752440,
-                                          0.55557023301960222474,
-                                          0.38268343236508977173,
-                                          0.19509032201612826785 };
-
-// Five radix-2 DIF stages on 32 registers (fft32.h: fft32_dif, in double): stage s pairs (k, k + h), h = 16 >> s; the lower
-// output owes W^(pos mod H) = the thread's value of the stage (TW: wsrc[s * pitch], coalesced) x the literal W_32^((k mod h) << s).
-// S0 > 0 skips the first S0 stages (pass C: the last R stages on 2^S0 groups of 32 >> S0 points).
-template <bool REV, bool TW, int S0 = 0> __device__ __forceinline__ void fft32_dif_d(double2 (&x)[32], const double2 *wsrc, uint32_t pitch)
-{
-#pragma unroll
-    for (int s = S0; s < 5; s++) {
-        const int h = 16 >> s;
-        double2 ws = double2{ 1.0, 0.0 };
-        if constexpr (TW)
-            ws = wsrc[s * pitch];
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            if ((k & h) != 0)
-                continue;
-            const double2 a = x[k], b = x[k + h];
-            x[k] = add2(a, b);
-            double2 d = sub2(a, b);
-            const int e = (k & (h - 1)) << s; // W_32 exponent, 0..15
-            if (e == 8) {
-                d = REV ? double2{ -d.y, d.x } : double2{ d.y, -d.x }; // -i / +i by swap and negate
-            } else if (e != 0) {
-                const double cr = kC32d[e], ci = REV ? kS32d[e] : -kS32d[e];
-                d = double2{ d.x * cr - d.y * ci, d.x * ci + d.y * cr };
-            }
-            if constexpr (TW)
-                d = cmul(d, ws);
-            x[k + h] = d;
-        }
-    }
 }
 
 // fft_big.hip's swizzle term for a position whose 32-block index (position >> (5 + R)) is k: k's five bits rotated by R
@@ -125,7 +61,7 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
     return ((k & ((1u << (5 - R)) - 1)) << R) | ((k >> (5 - R)) & ((1u << R) - 1));
 }
 
-template <int L, bool REV, bool NT>
+template <int L, bool REV, bool NT, bool R4 = false>
 __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(double2 *__restrict__ data, const double2 *__restrict__ tw,
                                                                            double scale, uint64_t batch)
 {
@@ -140,12 +76,13 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
     const uint64_t xform = blockIdx.x;
     if (xform >= batch)
         return;
-    const __amdgpu_buffer_rsrc_t rows = make_rows(data + xform * N, N * sizeof(double2));
+    static_assert(!R4 || L == 14 || L == 12, "radix-4 stages: N = 16384 = 4^7 and N = 4096 = 4^6");
+    const __amdgpu_buffer_rsrc_t rows = make_rows64(data + xform * N, N * sizeof(double2));
 
     double2 x[32];
 #pragma unroll
     for (int k = 0; k < 32; k++)
-        x[k] = row_load<NT>(rows, toff, T * k * sizeof(double2));
+        x[k] = row_load64<NT>(rows, toff, T * k * sizeof(double2));
 
     // LDS byte addresses of the three access patterns: fft_big.hip's, with 8-byte slots
     //   pattern A  position k*M + t          ->  8*k*M + (8t ^ 8*rot(k))                  rot(k) is a literal
@@ -162,7 +99,27 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
     const uint32_t base_c = (256u * w) | (8u * ((((w >> R) & ((1u << (5 - R)) - 1)) << R) | ((w >> 5) & ((1u << R) - 1))));
     const uint32_t base_a = 8u * t;
 
-    fft32_dif_d<REV, true>(x, tw + t, T); // pass A: tw = [pass][stage][thread]
+    [[maybe_unused]] auto tab = [&](int slot) { return tw[slot * T + t]; }; // radix-4 form: the thread's value of a table slot
+    if constexpr (R4) { // fft_big.hip's arrangement of the seven (six) stages: see the comments there
+        double2 thr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tab(q); // W_N^((q + 1) t)
+        r4_stage<REV, 4, 7, 2, true>(x, thr); // stage 0: quarter = register bits 4, 3; constant W_32^(q (k & 7))
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tab(3 + q); // W_(N/4)^((q + 1) t)
+        r4_stage<REV, 2, 1, 8, true>(x, thr); // stage 1: register bits 2, 1; constant W_8^(q (k & 1))
+        layer<1>(x); // stage 2, first layer: the quarter (1, 1) = odd registers of the upper half of the threads
+        const bool upper = t >= T / 2;
+#pragma unroll
+        for (int k = 1; k < 32; k += 2) {
+            const double2 r = rot_i<REV>(x[k]);
+            x[k] = double2{ upper ? r.x : x[k].x, upper ? r.y : x[k].y };
+        }
+    } else {
+        fft32_dif<REV, true, 0, true>(x, tw + t, T); // pass A: tw = [pass][stage][thread]
+    }
 
     // ---- exchange A -> B, one plane at a time
 #pragma unroll
@@ -184,7 +141,21 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
         __syncthreads();
     }
 
-    fft32_dif_d<REV, true>(x, tw + 5 * T + t, T); // pass B
+    if constexpr (R4) {
+        layer<16>(x); // stage 2, second layer: register bit 4
+        r4_split_twiddles<REV>(x, (blk & 1u) != 0, tab(6), tab(7), std::make_integer_sequence<int, 32>{});
+        double2 thr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tab(8 + q);
+        r4_stage<REV, 3, 3, 4, true>(x, thr); // stage 3: register bits 3, 2; constant W_16^(q (j & 3))
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            thr[q] = tab(11 + q);
+        r4_stage<REV, 1, 0, 0, true>(x, thr); // stage 4: register bits 1, 0; thread twiddles only
+    } else {
+        fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T); // pass B
+    }
 
     // ---- exchange B -> C
 #pragma unroll
@@ -207,7 +178,15 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
             __syncthreads();
     }
 
-    fft32_dif_d<REV, false, 5 - R>(x, tw, 0); // pass C: constants only
+    if constexpr (R4) {
+        if constexpr (R == 4) {
+            const double2 none[3] = {};
+            r4_stage<REV, 3, 3, 4, false>(x, none); // stage 5 (N = 16384): register bits 3, 2; constants W_16^(q (i & 3)) only
+        }
+        r4_layers<REV, 1>(x); // the last stage (register bits 1, 0): no twiddles
+    } else {
+        fft32_dif<REV, false, 5 - R>(x, tw, 0); // pass C: constants only
+    }
 
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
 #pragma unroll
@@ -217,14 +196,14 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
             o.x *= scale;
             o.y *= scale;
         }
-        row_store<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(double2), o);
+        row_store64<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(double2), o);
     }
 }
 
-template <int L, bool REV> int launch_l(const fft_reg_args &a, hipStream_t s)
+template <int L, bool REV, bool R4 = false> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = sizeof(double) << L;
-    auto kern = sdsp_fft_big_f64_kernel<L, REV, true>;
+    auto kern = sdsp_fft_big_f64_kernel<L, REV, true, R4>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<uint64_t> attr_done{ 0 };
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
@@ -241,13 +220,25 @@ template <int L, bool REV> int launch_l(const fft_reg_args &a, hipStream_t s)
 }
 } // namespace
 
-bool fft_big64_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384); }
+bool fft_big64_supports(uint32_t n, int radix)
+{
+    if (radix == 4)
+        return n == 4096 || n == 16384; // genuine radix-4 stages (the R4 form)
+    return radix == 2 && (n == 4096 || n == 8192 || n == 16384);
+}
 
 int launch_fft_big_f64(const fft_reg_args &a, void *stream)
 {
     if (a.batch == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a.radix == 4) { // a.tw: the radix-4 thread-twiddle table in double
+        if (a.n == 4096)
+            return a.reverse ? launch_l<12, true, true>(a, s) : launch_l<12, false, true>(a, s);
+        if (a.n == 16384)
+            return a.reverse ? launch_l<14, true, true>(a, s) : launch_l<14, false, true>(a, s);
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix-4 stages in double: N = 4096 / 16384");
+    }
     switch (a.n) {
     case 4096: return a.reverse ? launch_l<12, true>(a, s) : launch_l<12, false>(a, s);
     case 8192: return a.reverse ? launch_l<13, true>(a, s) : launch_l<13, false>(a, s);

@@ -222,3 +222,17 @@ def test_loader_refuses_a_library_built_from_other_sources(monkeypatch):
     monkeypatch.setenv("SDSP_HIP_NO_REBUILD", "1")
     with pytest.raises(L.StaleLibraryError):
         L.load()
+
+
+def test_source_hash_through_a_symlinked_checkout(tmp_path):
+    """the GPU box reaches the tree through a symlink (/root/repo -> scratch copy): the hash must not depend on the path
+    the package was imported by (a relative_to() on an unresolved __file__ raised there once)"""
+    import subprocess
+    import sys
+    link = tmp_path / "repo_link"
+    link.symlink_to(ROOT, target_is_directory=True)
+    code = ("import sys; sys.path.insert(0, %r); from simpledsp_amd import build as B; print(B.source_hash())" % str(link))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    from simpledsp_amd import build as B
+    assert r.stdout.strip() == B.source_hash()

@@ -307,8 +307,8 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
         want = oracle.fft(x, radix, rev)
         plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=2)
         fast = None  # round 3: sizes whose default is no longer the three-pass schedule (it became their variant 1)
-        if n == 1 << 14 and radix == 2:
-            fast = ("sdsp_fft_big_f64_kernel", 1)  # the registers-resident kernel in double
+        if n == 1 << 14:
+            fast = ("sdsp_fft_big_f64_kernel", 1)  # the registers-resident kernel in double (radix-2 or radix-4 stages)
         elif n >= 1 << 16:
             fast = ("sdsp_fft2p_cols+sdsp_fft2p_rows", 2)  # the two-pass kernels in double
         if fast:
@@ -321,7 +321,7 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
         assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
         # column step + the rows' own passes + untwist.  Rows of 1024 .. 16384 (radix 2) are one pass (N = 16384: the
         # registers-resident kernel in double, were three), rows of 2^15 three, rows of 2^16 two (the two-pass kernels in double)
-        rows_passes = {1 << 14: 1, 1 << 15: 1, 1 << 16: 1, 1 << 17: 1, 1 << 18: 1 if radix == 2 else 3, 1 << 19: 3, 1 << 20: 2}[n]
+        rows_passes = {1 << 14: 1, 1 << 15: 1, 1 << 16: 1, 1 << 17: 1, 1 << 18: 1, 1 << 19: 3, 1 << 20: 2}[n]
         assert plan.info.hbm_passes == 2 + rows_passes
         d = torch.from_numpy(x).cuda()
         plan.exec(d)
@@ -741,25 +741,27 @@ SIZE_TABLE = [
     (1 << 18, 4, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2), (1 << 19, 2, "f32", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2),
     (1 << 20, 2, "f32", "sdsp_fft1m_fused", 2, 2), (1 << 20, 4, "f32", "sdsp_fft1m_fused", 2, 2),
     (64, 4, "f64", "sdsp_fft_reg_f64_kernel", 1, 4), (1024, 2, "f64", "sdsp_fft_reg_f64_kernel", 1, 2),
-    (4096, 4, "f64", "sdsp_fft_reg_f64_kernel", 1, 4), (4096, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
+    (4096, 4, "f64", "sdsp_fft_big_f64_kernel", 1, 4), (4096, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
     (8192, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2), (16384, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
-    (16384, 4, "f64", "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 3, 24),
+    (16384, 4, "f64", "sdsp_fft_big_f64_kernel", 1, 4), (1 << 15, 2, "f64", "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 3, 2),
 ]
 
 
-@pytest.mark.parametrize("n,batch", [(4096, 5), (8192, 1), (8192, 7), (16384, 3)])
-def test_registers_resident_kernel_f64(sd, torch_cuda, oracle, n, batch):
-    """fft_big64.hip (round 3): N = 4096 / 8192 / 16384 in double, transform in registers, one HBM pass; held to the
-    reference's own bound 4 N eps against the oracle in both directions, and to the kernel it replaces as the default."""
+@pytest.mark.parametrize("n,radix,batch", [(4096, 2, 5), (8192, 2, 1), (8192, 2, 7), (16384, 2, 3), (4096, 4, 6), (16384, 4, 1), (16384, 4, 5)])
+def test_registers_resident_kernel_f64(sd, torch_cuda, oracle, n, radix, batch):
+    """fft_big64.hip (round 3): N = 4096 / 8192 / 16384 in double, transform in registers, one HBM pass -- radix-2 stages, and
+    genuine radix-4 stages for sdsp::fft_radix4 plans of N = 4096 / 16384 (the reference's own precision and stage type);
+    held to the reference's own bound 4 N eps against the oracle of the plan's radix in both directions, and to the kernel
+    it replaces as the default."""
     torch = torch_cuda
     rng = np.random.default_rng(n + batch)
     x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
     v_big = 0
     for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
-        want = oracle.fft(x, 2, rev)
-        plan = sd.FftPlan(n, 2, T, sd.F64, max_batch=batch)
+        want = oracle.fft(x, radix, rev)
+        plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=batch)
         plan.set_variant(v_big)
-        assert plan.info.kernel.decode() == "sdsp_fft_big_f64_kernel" and plan.info.hbm_passes == 1 and plan.info.stage_radix == 2
+        assert plan.info.kernel.decode() == "sdsp_fft_big_f64_kernel" and plan.info.hbm_passes == 1 and plan.info.stage_radix == radix
         d = torch.from_numpy(x).cuda()
         guard = torch.full((1 << 14,), 7.0 + 3.0j, dtype=torch.complex128, device="cuda")
         plan.exec(d)
