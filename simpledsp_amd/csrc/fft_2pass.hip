@@ -34,18 +34,6 @@ using namespace fft32;
 
 constexpr int kTile = 16; // sequences per tile
 
-// After a run of 64-bit LDS stores nothing may be scheduled in front of the wait for them: fft_big64.hip, lds_stores_done (a store
-// picks its data registers up after issue; the compiler reuses them at once for address arithmetic; seen as torn doubles on
-// some boxes: profiles/r03_lds_b64_hazard.md).  The f32 planes (ds_write_b32: one data dword) keep their schedule.
-template <typename Real> __device__ __forceinline__ void plane_stores_done()
-{
-    if constexpr (sizeof(Real) == 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 template <int BITS> __device__ __forceinline__ uint32_t brev_bits(uint32_t v) { return BITS == 0 ? 0u : (__brev(v) >> (32 - BITS)); }
 
 // W_N^m, N = 2^L, m < N: coarse factor from the LDS copy of W_1024, fine factor (angle < 2 pi / 1024) from a short series:
@@ -111,7 +99,6 @@ __device__ __forceinline__ void cols_tile2p(const C *in_x, C *ws_x, uint32_t til
 #pragma unroll
             for (int k = 0; k < 32; k++) // row u + T1 k: bit 5 of the row = bit of k (no carry from u < T1)
                 ((((k * T1) >> 5) & 1) ? w1 : w0)[16 * T1 * k] = half ? x[k].y : x[k].x;
-            plane_stores_done<Real>();
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 32; k++) {
@@ -232,7 +219,6 @@ __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t ti
                 else
                     ((k & 1) ? wb1 : wb0)[16 * (((k >> 1) ^ (k >> 2)) & 1) + 32 * (k >> 2)] = f;
             }
-            plane_stores_done<Real>();
             __syncthreads();
             {
                 uint32_t q = rx;

@@ -48,25 +48,17 @@ template <bool NT> __device__ __forceinline__ double2 row_load64(__amdgpu_buffer
     const unsigned int a = v.x, b = v.y, c = v.z, d = v.w;
     return double2{ __hiloint2double((int)b, (int)a), __hiloint2double((int)d, (int)c) };
 }
+// The row offset travels in the VECTOR offset here, not in soffset.  A buffer store of more than 64 bits whose data registers
+// are overwritten by the next VALU instruction needs a wait state in between; hipcc (ROCm 7.2) inserts it only when soffset is
+// NOT a register (the rule of older parts) -- with the row in an SGPR it emitted `buffer_store_dwordx4 v[32:35], v116, s[0:3], s54
+// offen nt` directly followed by `v_xor_b32 v32, 0xa0, v117`, and on some boxes, in some launches, the first data dword of a few
+// lanes left as that address temp: doubles with a correct high word and an LDS address as the low word, results off by ~2e-7
+// (profiles/r03_store_hazard.md).  With soffset = 0 the compiler's hazard recogniser covers the store.
 template <bool NT> __device__ __forceinline__ void row_store64(__amdgpu_buffer_rsrc_t rows, uint32_t thread_off, uint32_t row_off, double2 a)
 {
     const v4u_t v = { (unsigned)__double2loint(a.x), (unsigned)__double2hiint(a.x), (unsigned)__double2loint(a.y),
                       (unsigned)__double2hiint(a.y) };
-    __builtin_amdgcn_raw_buffer_store_b128(v, rows, thread_off, row_off, NT ? 2 : 0);
-}
-
-// A hazard found the hard way (round 3, profiles/r03_lds_b64_hazard.md): after a run of ds_write_b64 the compiler reuses the
-// stores' DATA registers at once -- x[j].y is dead once written -- for the next phase's address arithmetic, BEFORE the
-// s_waitcnt lgkmcnt(0) in front of the barrier.  An LDS store moves its operands to the LDS after issue (2 cycles per source
-// dword, MI355X_MICROARCH.md), and with 32 stores queued per wave and eight waves per CU a later VALU write could reach a
-// register before the store had picked up both dwords: on some boxes, in a few launches out of hundreds, 16 lanes of one wave
-// stored (address-temp, data-high) -- results off by ~2e-7, low dword = an LDS address.  So: nothing is scheduled between a
-// plane's stores and the wait for them.
-__device__ __forceinline__ void lds_stores_done()
-{
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rows, thread_off + row_off, 0, NT ? 2 : 0);
 }
 
 // fft_big.hip's swizzle term for a position whose 32-block index (position >> (5 + R)) is k: k's five bits rotated by R
@@ -143,7 +135,6 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
 #pragma unroll
         for (int k = 0; k < 32; k++)
             lds_f64(8u * k * M + (ta ^ (8u * rot5<R>(k)))) = half ? x[k].y : x[k].x;
-        lds_stores_done();
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 32; j++) {
@@ -180,7 +171,6 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
 #pragma unroll
         for (int j = 0; j < 32; j++)
             lds_f64(base_b[j % JL] + 256u * (j / JL)) = half ? x[j].y : x[j].x;
-        lds_stores_done();
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
