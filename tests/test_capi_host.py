@@ -236,3 +236,17 @@ def test_source_hash_through_a_symlinked_checkout(tmp_path):
     assert r.returncode == 0, r.stderr
     from simpledsp_amd import build as B
     assert r.stdout.strip() == B.source_hash()
+
+
+@pytest.mark.parametrize("src,flags", [("fft_big64.hip", []), ("fft_2pass.hip", [])])
+def test_no_wide_store_is_followed_by_a_write_to_its_data_registers(src, flags):
+    """profiles/r03_store_hazard.md: a vector-memory store of more than 64 bits whose data register is overwritten by the NEXT
+    instruction needs a wait state; the compiler inserts it for global stores and for buffer stores with an immediate soffset, not
+    for buffer stores whose soffset is an SGPR -- which is how fft_big64.hip once produced doubles with an LDS address as their low
+    word on some boxes.  tools/isa_store_hazard.py scans the device assembly for the pattern (no GPU needed)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_store_hazard.py"), str(ROOT / "simpledsp_amd" / "csrc" / src), *flags],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "unguarded overwrites of store data: 0" in r.stdout
