@@ -316,21 +316,6 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
             d0 = torch.from_numpy(x).cuda()
             plan.exec(d0)
             torch.cuda.synchronize()
-            ref_np = np.fft.ifft(x, axis=-1) if rev else np.fft.fft(x, axis=-1)
-            if not rel_max_err(d0.cpu().numpy(), want) < _tol64(n):
-                tw = plan.twiddles()
-                j = np.arange(n)
-                tw_ref = np.exp((2j if rev else -2j) * np.pi * j / n)
-                from conftest import ROOT
-                with open(ROOT / "gpurun_out" / "diag.txt", "a") as f:
-                    print(n, radix, rev, "gpu-oracle", rel_max_err(d0.cpu().numpy(), want), "gpu-numpy", rel_max_err(d0.cpu().numpy(), ref_np),
-                          "oracle-numpy", rel_max_err(want, ref_np), "plan row W_N vs exp:", np.abs(tw - tw_ref).max(), file=f)
-                np.save(ROOT / "gpurun_out" / "diag_got.npy", d0.cpu().numpy())
-                np.save(ROOT / "gpurun_out" / "diag_x.npy", x)
-                d1 = torch.from_numpy(x).cuda()  # the same plan again: is the deviation a property of the plan or of the run?
-                plan.exec(d1)
-                torch.cuda.synchronize()
-                np.save(ROOT / "gpurun_out" / "diag_got2.npy", d1.cpu().numpy())
             assert rel_max_err(d0.cpu().numpy(), want) < _tol64(n), (n, radix, rev)
             plan.set_variant(1)
         assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
@@ -782,9 +767,7 @@ def test_registers_resident_kernel_f64(sd, torch_cuda, oracle, n, radix, batch):
         plan.exec(d)
         torch.cuda.synchronize()
         got = d.cpu().numpy()
-        ref_np = np.fft.ifft(x, axis=-1) if rev else np.fft.fft(x, axis=-1)
-        assert rel_max_err(got, want) < _tol64(n), (n, rev, "gpu-oracle", rel_max_err(got, want), "gpu-numpy", rel_max_err(got, ref_np),
-                                                    "oracle-numpy", rel_max_err(want, ref_np))
+        assert rel_max_err(got, want) < _tol64(n), (n, rev, rel_max_err(got, want))
         assert bool((guard == 7.0 + 3.0j).all())
         plan.set_variant(1 - v_big)  # what served the size before
         assert plan.info.kernel.decode() != "sdsp_fft_big_f64_kernel"
