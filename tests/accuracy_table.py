@@ -20,7 +20,7 @@ def rel(got, ref):
 
 
 print("| kernel | case | max normwise error | bound |\n|---|---|---|---|")
-for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20):
+for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20, 1 << 21, 1 << 22):
     for radix in (2, 4, 0):
         if radix == 4 and not sd.isPowerOf4(n):
             continue
@@ -34,8 +34,27 @@ for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20):
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
             torch.cuda.synchronize()
-            errs.append(rel(d.cpu().numpy(), o.fft(x.astype(np.complex128), radix or 2, rev)))
+            x128 = x.astype(np.complex128)
+            ref = o.fft(x128, radix or 2, rev) if n <= (1 << 20) else (np.fft.ifft(x128, axis=-1) if rev else np.fft.fft(x128, axis=-1))
+            errs.append(rel(d.cpu().numpy(), ref))
         print(f"| `{plan.info.kernel.decode()}` | N = {n}, radix {radix}, fwd / rev | {errs[0]:.2e} / {errs[1]:.2e} | 1e-6 |")
+
+# double precision (round 3): against the oracle in units of the reference's own bound 4 N eps (testFFT.cpp:37)
+for n in (64, 1024, 4096, 8192, 16384, 1 << 16, 1 << 18, 1 << 20):
+    for radix in (2, 4):
+        if radix == 4 and not sd.isPowerOf4(n):
+            continue
+        batch = max(2, min(16, (1 << 16) // n))
+        x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
+        errs = []
+        for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+            plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=batch)
+            d = torch.from_numpy(x).cuda()
+            plan.exec(d)
+            torch.cuda.synchronize()
+            errs.append(rel(d.cpu().numpy(), o.fft(x, radix, rev)))
+        tol = 4 * n * np.finfo(np.float64).eps
+        print(f"| `{plan.info.kernel.decode()}` (f64) | N = {n}, radix {radix}, fwd / rev | {errs[0]:.2e} / {errs[1]:.2e} (= {errs[0] / tol:.3f} / {errs[1] / tol:.3f} of the bound) | 4 N eps = {tol:.1e} |")
 
 # cascaded biquads, BASELINE config-4 filter, f32
 x = rng.standard_normal((64, 4096)).astype(np.float32)
@@ -50,7 +69,7 @@ for c in range(64):
     f = o.iir(4)
     f.set_lp_coeff(10e3, 100e3)
     want.append(f.process(x[c].astype(np.float64)))
-print(f"| `sdsp_iir_supertile_kernel` | 4-section LP, 4096 samples, f32 | {rel(d.cpu().numpy(), np.array(want)):.2e} | 1e-6 (f64: bit-exact) |")
+print(f"| `{bank.kernel_name(d)}` | 4-section LP, 4096 samples, f32 | {rel(d.cpu().numpy(), np.array(want)):.2e} | 1e-6 (f64: bit-exact) |")
 
 # the same filter and a low cutoff (f0/fs = 0.005) in pure f32 and in the mixed mode (float samples, double recurrence)
 for f0 in (10e3, 500.0):
@@ -65,7 +84,7 @@ for f0 in (10e3, 500.0):
             f = o.iir(4)
             f.set_lp_coeff(f0, 100e3)
             want.append(f.process(x[c].astype(np.float64)))
-        print(f"| `sdsp_iir_supertile_kernel` | 4-section LP f0/fs = {f0 / 100e3:g}, 4096 samples, {name} | {rel(d.cpu().numpy(), np.array(want)):.2e} | "
+        print(f"| `{bank.kernel_name(d)}` | 4-section LP f0/fs = {f0 / 100e3:g}, 4096 samples, {name} | {rel(d.cpu().numpy(), np.array(want)):.2e} | "
               f"{'1e-6 (BASELINE filter only)' if prec == sd.F32 else '1.2e-7'} |")
 
 # FIR, f32
