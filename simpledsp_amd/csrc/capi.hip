@@ -232,6 +232,7 @@ inline bool big_is_default(uint32_t n, int radix) { return big_r4_form(n, radix)
 inline int big64_variant(uint32_t) { return 0; } // 4096: 73.2-73.6 % against 66.5-68.6 % (fft_reg64.hip), one call, round 3
 
 constexpr uint64_t kFft1mQueues = 8, kFft1mRing = 3; // persistent N = 2^20 kernel: ticket queues x intermediates per queue
+constexpr uint64_t kFused2pUnitsPerLaunch = 1024; // units (8 - 32 MiB each) one persistent launch covers (sizes the counter block)
 constexpr uint64_t kFft1mPerLaunch = 4096; // transforms one persistent launch covers (sizes the counter block)
 // Tables of fft_mix.hip (N = R x 4096, R = 2 / 4): the N = 4096 radix-4 thread-twiddle table built from W_4096^j = W_N^(R j),
 // and the leading stage's thread twiddles [q - 1][t] = W_N^(q t), q < R, t < 256 (R = 2) / 512 (R = 4).
@@ -284,8 +285,10 @@ struct sdsp_hip_fft_plan {
     uint64_t twiddle_bytes = 0;
     void *host_stage = nullptr;    // device staging buffer of the *_host path
     uint64_t host_stage_bytes = 0;
-    void *sync = nullptr;          // N = 2^20: the persistent kernel's ticket / arrival counters
-    uint64_t sync_count = 0;       // ... transforms one launch of it covers
+    void *sync = nullptr;          // persistent two-pass kernels: ticket / arrival counters
+    uint64_t sync_count = 0;       // ... units (N = 2^20 f32: transforms) one launch covers
+    uint64_t sticky_off = 0;       // ... byte offset of the sticky abort word behind the per-launch block
+    uint32_t f2_unit = 0, f2_queues = 0, f2_ring = 0, f2_lag = 0; // fft_2pass.hip's persistent schedule (0 = workspace too small)
     uint64_t wait_limit = 200000000ull; // ... and what a hand-off poll may take (100 MHz ticks: 2 s) before the launch gives up
     sdsp_hip_fft_plan *partner = nullptr; // reverse plan of the generic convolution path (lazy)
     sdsp_hip_fft_plan *mid_rows = nullptr; // N = 2^16 .. 2^19 f32: plan of the 16 row transforms (fft_mid.hip)
@@ -334,11 +337,16 @@ int ensure_workspace(sdsp_hip_fft_plan *p)
     return SDSP_HIP_OK;
 }
 
+// the persistent kernels' sticky abort word: set by any launch whose bounded hand-off wait gave up, cleared by
+// sdsp_hip_fft_exec at the start of a call (the per-launch abort flag beside the tickets is re-zeroed for every launch)
+void *fft1m_sticky(const sdsp_hip_fft_plan *p) { return reinterpret_cast<char *>(p->sync) + p->sticky_off; }
+
 // chunk sizes of the multi-pass schedules (shared by exec and the launch count)
 uint64_t fft1m_chunk(const sdsp_hip_fft_plan *p) { return std::max<uint64_t>(1, std::min<uint64_t>(32, p->ws_batch)); }
 uint64_t fft2p_chunk(const sdsp_hip_fft_plan *p) // an intermediate of at most 256 MiB per chunk
 {
-    return std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, (1ull << 28) / ((uint64_t)p->n * esize(p->precision))));
+    const uint64_t cap = 1ull << 28; // the Infinity Cache: 37 % at 256 MiB, 35 % at 128 / 192, 33 - 34 % at 288 MiB and beyond (profiles/r03_fft2p_chunk_lab.txt)
+    return std::max<uint64_t>(1, std::min<uint64_t>(p->ws_batch, cap / ((uint64_t)p->n * esize(p->precision))));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -361,6 +369,7 @@ enum fft_kernel_id {
     K_FFT1M_CHUNKED, // fft1m.hip: two launches per chunk of <= 32 transforms
     K_FFT1M_FUSED,   // fft1m.hip: one persistent launch (cfg 3)
     K_2PASS,         // fft_2pass.hip: N = N1 x N2, two passes
+    K_2PASS_FUSED,   // fft_2pass.hip: the same tiles in one persistent, ticketed launch
     K_MID,           // fft_mid.hip: 16-point column step + row plan + untwist
     K_FOUR_STEP,     // fft_tile.hip twice: the general four-step
     K_UNSUPPORTED,   // no kernel serves this (plan, variant)
@@ -438,8 +447,16 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
         return { K_FFT1M_FUSED, "sdsp_fft1m_fused", 2, 2, true, false };
     }
     const bool two_pass_size = fft_2pass_supports(p->n, p->precision);
-    if (p->path == PATH_FOUR_STEP && variant == 0 && two_pass_size)
+    // two schedules over the same tiles (bit-identical results): ONE persistent, ticketed launch (the workspace is a ring of
+    // intermediates inside the Infinity Cache; needs a plan whose workspace holds that ring) and two launches per chunk of
+    // 256 MiB.  Variant 0 is the one that measured faster at 1 AND 2 GiB batches in one call (profiles/r03_fft2p_fused_lab.txt),
+    // variant 3 the other
+    if (p->path == PATH_FOUR_STEP && two_pass_size && (variant == 0 || variant == 3)) {
+        const bool fused_first = fft_2pass_fused_preferred(p->n, p->precision);
+        if (p->f2_unit && (variant == 0) == fused_first)
+            return { K_2PASS_FUSED, "sdsp_fft2p_fused", 2, 2, true, false };
         return { K_2PASS, "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2, true, false };
+    }
     // three streaming passes, N = 16 x N2 with the rows on a tuned single-pass kernel (or, nested, on another plan)
     if (p->path == PATH_FOUR_STEP && p->mid_rows && variant == ((two_pass_size || (big64 && big64_variant(p->n) == 0)) ? 1 : 0)) {
         const fft_kernel_sel rows = select_kernel(p->mid_rows, p->mid_rows->variant);
@@ -609,7 +626,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.workspace = p->workspace;
             a.tw_1024 = p->tw1;
             a.sync = p->sync;
-            a.sticky = reinterpret_cast<char *>(p->sync) + fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues);
+            a.sticky = fft1m_sticky(p);
             a.spin_limit = p->wait_limit;
             a.count = std::min<uint64_t>(p->sync_count, batch - done);
             // a ring of 4 with pass 2 two steps behind measured 42.0-42.2 %, 3 / one step 41.4-41.6 % (profiles/r02_fft1m_lab.md)
@@ -624,6 +641,31 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         return SDSP_HIP_OK;
     }
 
+    // the two-pass sizes in one persistent launch per kFused2pUnitsPerLaunch units
+    if (sel.id == K_2PASS_FUSED) {
+        const uint64_t per_launch = p->sync_count * p->f2_unit;
+        for (uint64_t done = 0; done < batch; done += per_launch) {
+            fft_2pass_fused_args a;
+            a.data = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
+            a.workspace = p->workspace;
+            a.tw_1024 = p->tw1024;
+            a.sync = p->sync;
+            a.sticky = reinterpret_cast<char *>(p->sync) + p->sticky_off;
+            a.spin_limit = p->wait_limit;
+            a.count = std::min<uint64_t>(per_launch, batch - done);
+            a.n = p->n;
+            a.unit = p->f2_unit;
+            a.ring = p->f2_ring;
+            a.lag = p->f2_lag;
+            a.queues = p->f2_queues;
+            a.scale = (float)(1.0 / p->n);
+            a.scale_d = 1.0 / p->n;
+            a.reverse = rev;
+            if (int rc = launch_fft_2pass_fused(p->precision, a, stream))
+                return rc;
+        }
+        return SDSP_HIP_OK;
+    }
     // N = 2^16 .. 2^19, f32: two passes over HBM (fft_2pass.hip), in chunks whose intermediate is at most 256 MiB
     if (sel.id == K_2PASS) {
         const uint64_t chunk = fft2p_chunk(p);
@@ -764,6 +806,7 @@ uint64_t fft_launch_count(const sdsp_hip_fft_plan *p, uint64_t batch, int varian
     case K_FFT1M_CHUNKED: return 2 * ceil_div(batch, fft1m_chunk(p));
     case K_FFT1M_FUSED: return ceil_div(batch, p->sync_count);
     case K_2PASS: return 2 * ceil_div(batch, fft2p_chunk(p));
+    case K_2PASS_FUSED: return ceil_div(batch, p->sync_count * p->f2_unit);
     case K_FOUR_STEP: return 2 * ceil_div(batch, p->ws_batch);
     case K_MID: {
         uint64_t n = 0;
@@ -774,21 +817,15 @@ uint64_t fft_launch_count(const sdsp_hip_fft_plan *p, uint64_t batch, int varian
     default: return in_pieces ? ceil_div(batch, fft_piece(p, sel, batch)) : 1;
     }
 }
-// the persistent N = 2^20 kernel's sticky abort word: set by any launch whose bounded hand-off wait gave up, cleared by
-// sdsp_hip_fft_exec at the start of a call (the per-launch abort flag beside the tickets is re-zeroed for every launch)
-void *fft1m_sticky(const sdsp_hip_fft_plan *p)
-{
-    return reinterpret_cast<char *>(p->sync) + fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues);
-}
 
 int fft1m_check_sticky(sdsp_hip_fft_plan *p)
 {
-    if (p->path != PATH_FFT1M || !p->sync)
+    if (!p->sync)
         return SDSP_HIP_OK;
     unsigned flag = 0;
     HIP_TRY(hipMemcpy(&flag, fft1m_sticky(p), sizeof(flag), hipMemcpyDeviceToHost));
     if (flag)
-        return fail(SDSP_HIP_ERR_HIP, "an N = 2^20 launch gave up on a bounded wait between its two passes: the output of the last call is invalid");
+        return fail(SDSP_HIP_ERR_HIP, "a persistent two-pass launch gave up on a bounded wait between its passes: the output of the last call is invalid");
     return SDSP_HIP_OK;
 }
 
@@ -969,7 +1006,8 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);
             // + one line behind the per-launch block for the sticky abort word (never touched by the per-launch memset)
-            const size_t sync_bytes = fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues) + 64;
+            p->sticky_off = fft1m_sync_bytes(p->sync_count, (uint32_t)kFft1mQueues);
+            const size_t sync_bytes = p->sticky_off + 64;
             hipError_t e = hipMalloc(&p->sync, sync_bytes);
             if (e == hipSuccess) // the abort words must read 0 before the first persistent launch (sdsp_hip_fft_plan_status)
                 e = hipMemset(p->sync, 0, sync_bytes);
@@ -988,6 +1026,26 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         if (!rc) {
             make_twiddles(1024, direction, w);
             rc = upload_twiddles(w, precision, &p->tw1024);
+        }
+    }
+    // the two-pass sizes of fft_2pass.hip: counters of the persistent schedule, where the workspace holds its ring of intermediates
+    if (!rc && p->path == PATH_FOUR_STEP && fft_2pass_supports(n, precision)) {
+        uint32_t unit, queues, ring, lag;
+        fft_2pass_fused_shape(n, precision, &unit, &queues, &ring, &lag);
+        if (unit && p->ws_batch >= (uint64_t)unit * queues * ring) {
+            p->sync_count = std::min<uint64_t>((p->max_batch + unit - 1) / unit, kFused2pUnitsPerLaunch);
+            p->sticky_off = fft_2pass_sync_bytes(p->sync_count, queues);
+            hipError_t e = hipMalloc(&p->sync, p->sticky_off + 64);
+            if (e == hipSuccess)
+                e = hipMemset(p->sync, 0, p->sticky_off + 64);
+            if (e != hipSuccess)
+                rc = fail(SDSP_HIP_ERR_NOMEM, std::string("fft_2pass counters hipMalloc: ") + hipGetErrorString(e));
+            else {
+                p->f2_unit = unit;
+                p->f2_queues = queues;
+                p->f2_ring = ring;
+                p->f2_lag = lag;
+            }
         }
     }
     // plans whose DEFAULT kernel is multi-pass own their workspace from here on (no allocation on the launch path: stream
@@ -1091,7 +1149,7 @@ int sdsp_hip_fft_exec(sdsp_hip_fft_plan *p, void *data, uint64_t batch, void *st
         return fail(SDSP_HIP_ERR_INVALID_ARG, "data must be aligned to one complex element");
     if (int rc = use_device(p->device))
         return rc;
-    if (p->path == PATH_FFT1M && p->sync) // this call's launches report into a clean sticky abort word
+    if (p->sync) // this call's launches report into a clean sticky abort word
         HIP_TRY(hipMemsetAsync(fft1m_sticky(p), 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)));
     return fft_exec_pieces(p, data, batch, reinterpret_cast<hipStream_t>(stream), p->variant);
 }
@@ -1117,7 +1175,7 @@ int sdsp_hip_fft_exec_host(sdsp_hip_fft_plan *p, void *host_data, uint64_t batch
         p->host_stage_bytes = bytes;
     }
     HIP_TRY(hipMemcpy(p->host_stage, host_data, bytes, hipMemcpyHostToDevice));
-    if (p->path == PATH_FFT1M && p->sync)
+    if (p->sync)
         HIP_TRY(hipMemsetAsync(fft1m_sticky(p), 0, sizeof(unsigned), nullptr));
     if (int rc = fft_exec_device(p, p->host_stage, batch, nullptr, p->variant))
         return rc;

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fft32.h"
+#include "handoff.h"
 
 namespace sdsp_hip
 {
@@ -56,12 +57,7 @@ enum ws_layout { WS_ROWS = 0, WS_BLOCKED = 1 };
 // XCD's L2) -- the hand-off form of cdna_hip_programming.md Guideline 16 (R1) that needs no release fence.  (16-byte
 // write-through stores, two columns per lane after a DPP lane swap, measured no faster: 40.9 / 41.7 % against 41.4 / 42.2 %.)
 enum ws_access { WS_SC1_STORES = 2 };
-__device__ __forceinline__ void ws_store_sc1(float2 *p, float2 v)
-{
-    unsigned long long bits;
-    __builtin_memcpy(&bits, &v, 8);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ void ws_store_sc1(float2 *p, float2 v) { handoff::wt_store(p, v); }
 // What a tile does.  MODE_FFT is the product.  The other two exist for tools/lab_fft1m.hip only: the same loads and
 // stores without the butterflies (MODE_MOVE), and without the intermediate's traffic either (MODE_HBM_ONLY: what the
 // HBM-facing halves of the two passes cost on their own).
@@ -362,35 +358,9 @@ struct fused_args {
     float scale;
     unsigned long long spin_limit; // wall_clock64 ticks (100 MHz) a poll may take before it gives up
 };
-__host__ __device__ constexpr size_t fused_sync_words(uint32_t count, uint32_t queues) { return 32ull * (queues + 1) + 32ull * count; }
-
-__device__ __forceinline__ unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ONE lane waits until *word >= target (or the launch is aborted); returns false when it gave up
-__device__ __forceinline__ bool poll_geq(unsigned *word, unsigned target, unsigned *abort_flag, unsigned *sticky,
-                                         unsigned long long limit, uint32_t extra_sleep)
-{
-    if (ld_relaxed(word) >= target)
-        return true;
-    const unsigned long long t0 = wall_clock64();
-    for (unsigned it = 0;; it++) {
-        __builtin_amdgcn_s_sleep(8);
-        for (uint32_t i = 0; i < extra_sleep; i++)
-            __builtin_amdgcn_s_sleep(8);
-        if (ld_relaxed(word) >= target)
-            return true;
-        if ((it & 31) == 31) { // the give-up checks are rare: they must not add traffic to the hot words
-            if (ld_relaxed(abort_flag) != 0)
-                return false;
-            if (wall_clock64() - t0 > limit) {
-                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sticky)
-                    __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-}
+__host__ __device__ constexpr size_t fused_sync_words(uint32_t count, uint32_t queues) { return handoff::sync_words(count, queues); }
+using handoff::ld_relaxed;
+using handoff::poll_geq;
 
 template <bool REV, int MODE, int LAYOUT>
 __global__ __launch_bounds__(kThreads, 4) void sdsp_fft1m_fused(fused_args a)

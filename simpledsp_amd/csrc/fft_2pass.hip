@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fft32.h"
+#include "handoff.h"
 #include "sdsp_hip_internal.h"
 
 namespace sdsp_hip
@@ -61,12 +62,14 @@ template <int L, bool REV> __device__ __forceinline__ double2 twiddle_n(const do
 // ---- pass 1: 16 columns of one transform; 16 * T1 threads ----------------------------------------------------
 // in_x / ws_x: the transform's input matrix / its intermediate.  LDS: plane N1 x 16 floats, w1k = W_1024 (8 KiB, staged by
 // the caller), qtab 32 x 16 float2 (4 KiB)
-template <int L, int L1, bool REV, typename C>
-__device__ __forceinline__ void cols_tile2p(const C *in_x, C *ws_x, uint32_t tile, typename w32<C>::real *plane, const C *w1k, C *qtab)
+// t: the thread's index within the tile's 16 * T1 threads (the persistent kernel runs tiles side by side in one workgroup);
+// WT: write-through stores of the intermediate (the persistent kernel's hand-off, handoff.h)
+template <int L, int L1, bool REV, typename C, bool WT = false>
+__device__ __forceinline__ void cols_tile2p(const C *in_x, C *ws_x, uint32_t tile, typename w32<C>::real *plane, const C *w1k, C *qtab,
+                                            uint32_t t)
 {
     using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T1 = N1 / 32;
-    const uint32_t t = threadIdx.x;
     const uint32_t c = t & 15, u = t >> 4; // u < T1
     const uint32_t n2 = tile * kTile + c;
 
@@ -125,7 +128,11 @@ __device__ __forceinline__ void cols_tile2p(const C *in_x, C *ws_x, uint32_t til
         if ((k & 7) == 0)
             __builtin_amdgcn_sched_barrier(0);
         const int j = (int)(__brev((uint32_t)k) >> 27);
-        *at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff) = cmul(x[k], cmul(pw, qcol[16 * j]));
+        const C v = cmul(x[k], cmul(pw, qcol[16 * j]));
+        if constexpr (WT)
+            handoff::wt_store(at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff), v);
+        else
+            *at(dst_tile + (size_t)j * (16 << (L1 - 5)), soff) = v;
     }
 }
 template <typename C> __device__ __forceinline__ void stage_w1k2p(C *w1k, const C *tw_1024, uint32_t threads)
@@ -146,19 +153,18 @@ __global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const
     C *w1k = reinterpret_cast<C *>(sdsp_fft2p_smem + (size_t)N1 * kTile * sizeof(Real));
     stage_w1k2p(w1k, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    cols_tile2p<L, L1, REV, C>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024);
+    cols_tile2p<L, L1, REV, C>(in + xoff, ws + xoff, blockIdx.x % TILES, plane, w1k, w1k + 1024, threadIdx.x);
 }
 
 // ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
 // LDS: plane 16 x N2 floats; wrow = pass 2's thread twiddles [stage][lane] (5 x 32 float2, staged by the caller)
 template <int L, int L1, bool REV, typename C>
 __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t tile, typename w32<C>::real *plane, const C *wrow,
-                                            typename w32<C>::real scale)
+                                            typename w32<C>::real scale, uint32_t t)
 {
     using Real = typename w32<C>::real;
     constexpr uint32_t ES = (uint32_t)sizeof(C);
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32;
-    const uint32_t t = threadIdx.x;
 
     // first register pass: T2 lanes run along a row; element n2 = ua + T2 k of row k1 = 16 tile + ra lives at
     // [(n2 >> 4)][k1][n2 & 15] of the intermediate
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(c
     C *wrow = reinterpret_cast<C *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(Real));
     stage_wrow2p<L2>(wrow, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    rows_tile2p<L, L1, REV, C>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
+    rows_tile2p<L, L1, REV, C>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale, threadIdx.x);
 }
 
 template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_args &a, hipStream_t s)
@@ -341,7 +347,7 @@ template <bool REV> __device__ __forceinline__ void top_stage64(float2 (&lo)[32]
 
 // ---- pass 1 with N1 = 2048: 16 columns, 512 threads.  LDS: plane 2048 x 16 floats (slot = (row * 16 + col) ^ (((row >> 6) & 1) << 4)),
 // w1k = W_1024 (8 KiB), qtab 64 x 16 float2 (8 KiB)
-template <int L, bool REV>
+template <int L, bool REV, bool WT = false>
 __device__ __forceinline__ void cols64_tile2p(const float2 *in_x, float2 *ws_x, uint32_t tile, float *plane, const float2 *w1k, float2 *qtab)
 {
     constexpr int L1 = 11, L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
@@ -415,8 +421,14 @@ __device__ __forceinline__ void cols64_tile2p(const float2 *in_x, float2 *ws_x, 
         if ((j & 7) == 0)
             __builtin_amdgcn_sched_barrier(0);
         const int jj = (int)(__brev((uint32_t)j) >> 27) << 1;
-        *at(dst_tile + (size_t)jj * 512, soff) = cmul(lo[j], cmul(pw, qcol[16 * jj]));
-        *at(dst_tile + (size_t)(jj + 1) * 512, soff) = cmul(hi[j], cmul(pw, qcol[16 * (jj + 1)]));
+        const float2 v = cmul(lo[j], cmul(pw, qcol[16 * jj])), w = cmul(hi[j], cmul(pw, qcol[16 * (jj + 1)]));
+        if constexpr (WT) {
+            handoff::wt_store(at(dst_tile + (size_t)jj * 512, soff), v);
+            handoff::wt_store(at(dst_tile + (size_t)(jj + 1) * 512, soff), w);
+        } else {
+            *at(dst_tile + (size_t)jj * 512, soff) = v;
+            *at(dst_tile + (size_t)(jj + 1) * 512, soff) = w;
+        }
     }
 }
 template <int L, bool REV>
@@ -556,6 +568,264 @@ template <int L, bool REV> int launch_pair64(const fft_2pass_args &a, hipStream_
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
+// ================================================================================================================
+// Round 3, second part: the two passes in ONE persistent, ticketed launch -- the schedule of sdsp_fft1m_fused
+// (fft1m_kernels.h) over the tiles above, for every two-pass size.  A ticket step covers one UNIT = `unit` consecutive
+// transforms (8 MiB of data where a transform is smaller than that): its pass-1 items, then the pass-2 items of the unit
+// `lag` steps behind in the same queue.  A unit's intermediates live in slot (q * ring + i % ring) of the workspace, so the
+// intermediates in flight stay inside the Infinity Cache (queues x ring x unit bytes <= 256 MiB) and are consumed a few
+// microseconds after they were produced, instead of after a whole chunk's pass 1 (fft2p_chunk: 256 MiB written, then read).
+// Where the two passes have different thread counts (N1 != N2) the workgroup has the larger one and the shorter pass runs
+// G tiles side by side (whole waves each; the barriers inside a tile function are workgroup barriers either way).
+// Hand-off, synchronisation words, bounded polls, abort / sticky words: handoff.h, exactly as in sdsp_fft1m_fused.
+struct fused2p_kargs {
+    void *data;          // count transforms, in place
+    void *ws;            // queues x ring x unit transforms
+    const void *tw_1024;
+    unsigned *sync;
+    unsigned *sticky;    // nullable
+    uint32_t count, unit, ring, lag, queues;
+    uint32_t flags;      // 8 = fault injection (tests): every hand-off wait gives up at once
+    float scale;
+    double scale_d;
+    unsigned long long spin_limit;
+};
+
+// the thread index as a value the compiler cannot prove loop-invariant: the per-thread addresses of BOTH tile functions would
+// otherwise be hoisted out of the persistent loop and stay live across every tile (16 - 64 bytes of scratch per lane in f32)
+__device__ __forceinline__ uint32_t fresh_tid()
+{
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+// what the persistent kernel needs to know about a size: both passes on 32 points per thread (cols_tile2p / rows_tile2p)
+template <int L_, int L1_, typename C_> struct shape32 {
+    using C = C_;
+    using Real = typename w32<C>::real;
+    static constexpr int L = L_, L1 = L1_, L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
+    static constexpr int THREADS_C = kTile * (N1 / 32), THREADS_R = kTile * (N2 / 32);
+    static constexpr int THREADS = THREADS_C > THREADS_R ? THREADS_C : THREADS_R;
+    static constexpr int GC = THREADS / THREADS_C, GR = THREADS / THREADS_R; // tiles side by side in one item
+    static constexpr int MIN_WAVES = sizeof(Real) == 4 ? 4 : 2; // per SIMD: <= 128 VGPRs in f32 (as the two-launch kernels), <= 256 in double
+    static constexpr int ITEMS_C = (N2 / kTile) / GC, ITEMS_R = (N1 / kTile) / GR; // per transform
+    static constexpr size_t PLANE = (size_t)(N1 > N2 ? N1 : N2) * kTile * sizeof(Real);
+    // LDS: plane | W_1024 | qtab (pass 1's column twiddles, G tiles).  Pass 2's thread twiddles (1.25 / 2.5 KiB) are rebuilt from
+    // the W_1024 copy into the qtab area by every pass-2 item (qtab is dead then; the barrier inside rows_tile2p covers it), and
+    // the ticket mailbox lies over the plane's first 16 bytes -- the plane is dead between items, a tile function's own barrier
+    // separates the workgroup's read of the ticket from the first plane write, and the barrier that ends every item separates
+    // the last plane read from the next ticket's write.  That keeps N = 2^19 f32 at 80 KiB (two workgroups per CU) and fits
+    // N = 2^19 in double into the CU's 160 KiB.
+    static constexpr size_t W1K = PLANE, QTAB = W1K + 1024 * sizeof(C), WROW = QTAB, MAIL = 0;
+    static constexpr size_t LDS = QTAB + (size_t)GC * 32 * kTile * sizeof(C);
+    static_assert(5 * 32 * sizeof(C) <= (size_t)GC * 32 * kTile * sizeof(C), "pass 2's thread twiddles fit the qtab area");
+    template <bool REV> static __device__ __forceinline__ void stage(unsigned char *smem, const C *tw_1024)
+    {
+        stage_w1k2p(reinterpret_cast<C *>(smem + W1K), tw_1024, THREADS);
+    }
+    template <bool REV> static __device__ __forceinline__ void cols(const C *in_x, C *ws_x, uint32_t item, unsigned char *smem)
+    {
+        const uint32_t tid = fresh_tid();
+        const uint32_t g = tid / THREADS_C, t = tid % THREADS_C;
+        cols_tile2p<L, L1, REV, C, true>(in_x, ws_x, item * GC + g, reinterpret_cast<Real *>(smem) + (size_t)g * N1 * kTile,
+                                         reinterpret_cast<const C *>(smem + W1K), reinterpret_cast<C *>(smem + QTAB) + g * 32 * kTile, t);
+    }
+    template <bool REV> static __device__ __forceinline__ void rows(const C *ws_x, C *out_x, uint32_t item, unsigned char *smem, Real scale)
+    {
+        const uint32_t tid = fresh_tid();
+        const uint32_t g = tid / THREADS_R, t = tid % THREADS_R;
+        stage_wrow2p<L2>(reinterpret_cast<C *>(smem + WROW), reinterpret_cast<const C *>(smem + W1K), THREADS);
+        rows_tile2p<L, L1, REV, C>(ws_x, out_x, item * GR + g, reinterpret_cast<Real *>(smem) + (size_t)g * N2 * kTile,
+                                   reinterpret_cast<const C *>(smem + WROW), scale, t);
+    }
+};
+// N = 2^21 (1024 x 2048) and 2^22 (2048 x 2048), f32: the 64-points-per-thread passes
+template <int L_> struct shape64 {
+    using C = float2;
+    using Real = float;
+    static constexpr int L = L_, L1 = L == 21 ? 10 : 11, N1 = 1 << L1, N2 = 2048;
+    static constexpr int THREADS = 512, ITEMS_C = N2 / kTile, ITEMS_R = N1 / kTile, MIN_WAVES = 2;
+    static constexpr size_t PLANE = (size_t)2048 * kTile * 4;
+    static constexpr size_t W1K = PLANE, QTAB = W1K + 1024 * 8, WROW = QTAB + (size_t)64 * kTile * 8;
+    static constexpr size_t MAIL = WROW + 6 * 32 * 8, LDS = MAIL + 16;
+    template <bool REV> static __device__ __forceinline__ void stage(unsigned char *smem, const float2 *tw_1024)
+    {
+        stage_w1k2p(reinterpret_cast<float2 *>(smem + W1K), tw_1024, THREADS);
+        float2 *wrow = reinterpret_cast<float2 *>(smem + WROW);
+        for (uint32_t i = threadIdx.x; i < 6 * 32; i += THREADS)
+            wrow[i] = i < 5 * 32 ? tw_1024[(i & 31u) << (i >> 5)] : w2048<REV>(tw_1024, i & 31u);
+    }
+    template <bool REV> static __device__ __forceinline__ void cols(const float2 *in_x, float2 *ws_x, uint32_t item, unsigned char *smem)
+    {
+        float *plane = reinterpret_cast<float *>(smem);
+        const float2 *w1k = reinterpret_cast<const float2 *>(smem + W1K);
+        float2 *qtab = reinterpret_cast<float2 *>(smem + QTAB);
+        if constexpr (L1 == 10)
+            cols_tile2p<L, 10, REV, float2, true>(in_x, ws_x, item, plane, w1k, qtab, fresh_tid());
+        else
+            cols64_tile2p<L, REV, true>(in_x, ws_x, item, plane, w1k, qtab);
+    }
+    template <bool REV> static __device__ __forceinline__ void rows(const float2 *ws_x, float2 *out_x, uint32_t item, unsigned char *smem, float scale)
+    {
+        rows64_tile2p<L, L1, REV>(ws_x, out_x, item, reinterpret_cast<float *>(smem), reinterpret_cast<const float2 *>(smem + WROW), scale);
+    }
+};
+
+template <class S, bool REV> __global__ __launch_bounds__(S::THREADS, S::MIN_WAVES) void sdsp_fft2p_fused(fused2p_kargs a)
+{
+    using C = typename S::C;
+    using Real = typename S::Real;
+    using handoff::ld_relaxed;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
+    // mailbox: [0], [1] the item's ticket, alternating per iteration (an iteration without work has no barrier between the
+    // other waves' read of its ticket and lane 0's write of the next one); [2] go / abort of the item's wait
+    unsigned *mail = reinterpret_cast<unsigned *>(sdsp_fft2p_smem + S::MAIL);
+
+    const uint32_t n_units = (a.count + a.unit - 1) / a.unit;
+    const uint32_t q = blockIdx.x % a.queues;
+    if (q >= n_units)
+        return;
+    const uint32_t n_q = (n_units - q + a.queues - 1) / a.queues; // units of this queue
+    unsigned *const ticket_ctr = a.sync + 32 * q, *const abort_flag = a.sync + 32 * a.queues;
+    unsigned *const done = a.sync + 32 * (a.queues + 1);
+    const unsigned items_c = a.unit * S::ITEMS_C, items_r = a.unit * S::ITEMS_R, per_step = items_c + items_r;
+    const unsigned n_tickets = (n_q + a.lag) * per_step;
+
+    S::template stage<REV>(sdsp_fft2p_smem, reinterpret_cast<const C *>(a.tw_1024));
+    unsigned next = 0;
+    if (threadIdx.x == 0)
+        next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    for (unsigned it = 0;; it++) {
+        // ---- this item's ticket (drawn one item ahead, so the atomic's latency hides behind the previous tile).  A workgroup
+        // only ever waits for LOWER tickets of its queue, each of which is held by a running workgroup or done: the grid drains
+        // whatever its size and the dispatch order.  (Drawing blocks of 2 / 4 / 8 consecutive tickets per atomic measured 1 - 2 /
+        // 5 - 7 / 10 - 14 points slower at every size: a block keeps its later tickets waiting behind its first.)
+        if (threadIdx.x == 0)
+            mail[it & 1] = next;
+        __syncthreads(); // also: every wave has finished the previous item (planes / tables are free), tables are staged
+        const unsigned ticket = mail[it & 1];
+        if (ticket >= n_tickets)
+            break;
+        if (threadIdx.x == 0)
+            next = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned step = ticket / per_step, sub = ticket % per_step;
+        const bool first = sub < items_c;
+        const unsigned i = first ? step : step - a.lag; // wraps for the leading pass-2 slots: filtered below
+        if (i >= n_q)
+            continue; // ramp-up / ramp-down slot without work (uniform)
+        const unsigned item = first ? sub : sub - items_c;
+        const unsigned x_in = item / (first ? S::ITEMS_C : S::ITEMS_R), item_x = item % (first ? S::ITEMS_C : S::ITEMS_R);
+        const unsigned unit_id = q + i * a.queues;
+        const unsigned xf = unit_id * a.unit + x_in;
+        if (xf >= a.count)
+            continue; // the batch's last unit may be short (its arrival target below counts what exists)
+        const unsigned cnt = min(a.unit, a.count - unit_id * a.unit);
+        C *const ws_x = reinterpret_cast<C *>(a.ws) + (((size_t)(q * a.ring + i % a.ring) * a.unit + x_in) << S::L);
+        C *const data_x = reinterpret_cast<C *>(a.data) + ((size_t)xf << S::L);
+
+        // ---- wait for what this item depends on (ONE lane polls; ONE acquire for the workgroup)
+        unsigned *wait_word = nullptr;
+        unsigned target = 0;
+        if (!first) {
+            wait_word = done + 32 * unit_id; // the whole intermediate of this unit
+            target = cnt * S::ITEMS_C;
+        } else if (i >= a.ring) {
+            wait_word = done + 32 * (unit_id - a.ring * a.queues) + 16; // the ring slot's previous tenant (a full unit) has been read
+            target = a.unit * S::ITEMS_R;
+        }
+        if (wait_word) {
+            if (threadIdx.x == 0) {
+                bool ok;
+                if (a.flags & 8u) { // injected fault: behave exactly like a poll whose bound expired
+                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.sticky)
+                        __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                } else {
+                    ok = handoff::poll_geq(wait_word, target, abort_flag, a.sticky, a.spin_limit, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                mail[2] = ok ? 1u : 0u;
+            }
+            __syncthreads();
+            if (mail[2] == 0u)
+                break; // aborted: drain (uniform)
+        }
+
+        if (first)
+            S::template cols<REV>(data_x, ws_x, item_x, sdsp_fft2p_smem);
+        else
+            S::template rows<REV>(ws_x, data_x, item_x, sdsp_fft2p_smem, sizeof(Real) == 8 ? (Real)a.scale_d : (Real)a.scale);
+
+        // ---- publish: pass 1 hands its output to other workgroups (write-through stores: drained = at the fabric); pass 2
+        // frees the ring slot -- its loads of the slot have returned (their values fed the butterflies)
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(done + 32 * unit_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(done + 32 * unit_id + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <class S, bool REV> int launch_fused_s(const fft_2pass_fused_args &a, hipStream_t s)
+{
+    auto kern = sdsp_fft2p_fused<S, REV>;
+    static std::atomic<uint64_t> lds_done{ 0 };
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), S::LDS, lds_done))
+        return rc;
+    // as many workgroups as are resident (a larger grid would be correct too: tickets are drawn by running workgroups only);
+    // per device: a node may mix parts with different CU counts
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, "hipGetDevice failed");
+    int grid = cached[dev & 63].load();
+    if (!grid) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, S::THREADS, S::LDS) != hipSuccess || per_cu < 1 ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(SDSP_HIP_ERR_HIP, "fft_2pass fused: occupancy query failed");
+        grid = per_cu * prop.multiProcessorCount;
+        cached[dev & 63].store(grid);
+    }
+    const uint64_t units = (a.count + a.unit - 1) / a.unit;
+    fused2p_kargs k;
+    k.data = a.data;
+    k.ws = a.workspace;
+    k.tw_1024 = a.tw_1024;
+    k.sync = reinterpret_cast<unsigned *>(a.sync);
+    k.sticky = reinterpret_cast<unsigned *>(a.sticky);
+    k.count = (uint32_t)a.count;
+    k.unit = a.unit;
+    k.ring = a.ring;
+    k.lag = a.lag;
+    k.queues = a.queues;
+    k.flags = a.spin_limit == 0 ? 8u : 0u;
+    k.scale = a.scale;
+    k.scale_d = a.scale_d;
+    k.spin_limit = a.spin_limit;
+    hipError_t e = hipMemsetAsync(a.sync, 0, fft_2pass_sync_bytes(units, a.queues), s);
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass fused memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(S::THREADS), S::LDS, s, k);
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass fused launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
+template <class S> int launch_fused_dir(const fft_2pass_fused_args &a, hipStream_t s)
+{
+    return a.reverse ? launch_fused_s<S, true>(a, s) : launch_fused_s<S, false>(a, s);
+}
+
 template <int L, int L1, typename C> int launch_dir(const fft_2pass_args &a, hipStream_t s)
 {
     return a.reverse ? launch_pair<L, L1, true, C>(a, s) : launch_pair<L, L1, false, C>(a, s);
@@ -597,6 +867,68 @@ int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream)
     case 1u << 19: return launch_dir<19, 9, float2>(a, s);  //  512 x 1024
     case 1u << 21: return a.reverse ? launch_pair64<21, true>(a, s) : launch_pair64<21, false>(a, s); // 1024 x 2048
     case 1u << 22: return a.reverse ? launch_pair64<22, true>(a, s) : launch_pair64<22, false>(a, s); // 2048 x 2048
+    default: break;
+    }
+    return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
+}
+size_t fft_2pass_sync_bytes(uint64_t units, uint32_t queues) { return handoff::sync_words((uint32_t)units, queues) * sizeof(unsigned); }
+
+// the default schedule of a size: unit = transforms per ticket step (8 MiB of data, or one transform where it is larger), and
+// queues x ring units of intermediate = 256 MiB (the Infinity Cache), pass 2 trailing pass 1 by ring - 2 steps
+void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *queues, uint32_t *ring, uint32_t *lag)
+{
+    const uint64_t bytes = (uint64_t)n * (precision == SDSP_HIP_F64 ? 16 : 8);
+    *unit = *queues = *ring = *lag = 0;
+    if (!fft_2pass_supports(n, precision))
+        return;
+    *unit = (uint32_t)std::max<uint64_t>(1, (8ull << 20) / bytes);
+    const uint64_t unit_bytes = *unit * bytes;
+    *ring = 4;
+    *lag = 2;
+    *queues = (uint32_t)std::max<uint64_t>(2, (256ull << 20) / (unit_bytes * *ring));
+}
+
+// Persistent launch against two launches per chunk, same call, % of HBM peak on the compulsory bytes at 1 GiB / 2 GiB batches
+// (tools/lab_fft2p_fused.py, profiles/r03_fft2p_fused_lab.txt; p = persistent, c = chunked):
+//   f32  2^16: p 30.8 c 37.5 (2 GiB)      2^17: 35.7 v 35.6 / 40.0 v 36.9     2^18: 36.0 v 37.0 / 39.6 v 38.0     2^19: 37.2 v 36.0 / 40.7 v 37.7
+//        2^21: 32.7 v 32.3 / 35.0 v 33.1   2^22: 32.0 v 29.2 / 33.8 v 30.3
+//   f64  2^16: 35.4 v 36.2 / 37.9 v 37.1   2^17: 35.7 v 36.2 / 38.0 v 37.0     2^18: 35.5 v 33.8 / 37.9 v 34.6     2^19: 36.0 v 32.6 / 38.0 v 33.7
+//        2^20: 36.4 v 34.1 / 38.2 v 34.3
+// The persistent launch pays per item (two barriers, a drained store queue before the hand-off), which small tiles feel
+// (2^16: 32 KiB items), and a ramp at either end of the batch, which short batches feel.  Default where it won at both sizes.
+bool fft_2pass_fused_preferred(uint32_t n, int precision)
+{
+    if (precision == SDSP_HIP_F64)
+        return n >= (1u << 18) && n <= (1u << 20);
+    return n == (1u << 17) || n == (1u << 19) || n == (1u << 21) || n == (1u << 22);
+}
+
+// both passes over `count` transforms in ONE persistent launch (the workspace holds queues x ring x unit intermediates)
+int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *stream)
+{
+    if (a.count == 0)
+        return SDSP_HIP_OK;
+    if (a.ring == 0 || a.lag >= a.ring || a.queues == 0 || a.unit == 0 || a.count > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_2pass fused: need lag < ring, queues > 0, unit > 0 and a sane count");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (precision == SDSP_HIP_F64) {
+        switch (a.n) {
+        case 1u << 16: return launch_fused_dir<shape32<16, 8, double2>>(a, s);
+        case 1u << 17: return launch_fused_dir<shape32<17, 8, double2>>(a, s);
+        case 1u << 18: return launch_fused_dir<shape32<18, 9, double2>>(a, s);
+        case 1u << 19: return launch_fused_dir<shape32<19, 9, double2>>(a, s);
+        case 1u << 20: return launch_fused_dir<shape32<20, 10, double2>>(a, s);
+        default: break;
+        }
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
+    }
+    switch (a.n) {
+    case 1u << 16: return launch_fused_dir<shape32<16, 8, float2>>(a, s);
+    case 1u << 17: return launch_fused_dir<shape32<17, 8, float2>>(a, s);
+    case 1u << 18: return launch_fused_dir<shape32<18, 9, float2>>(a, s);
+    case 1u << 19: return launch_fused_dir<shape32<19, 9, float2>>(a, s);
+    case 1u << 21: return launch_fused_dir<shape64<21>>(a, s);
+    case 1u << 22: return launch_fused_dir<shape64<22>>(a, s);
     default: break;
     }
     return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");

@@ -168,6 +168,29 @@ struct fft1m_fused_args {
 size_t fft1m_sync_bytes(uint64_t count, uint32_t queues);
 int launch_fft1m_fused(const fft1m_fused_args &a, void *stream);
 
+// the two-pass sizes of fft_2pass.hip in ONE persistent, ticketed launch (the schedule of launch_fft1m_fused; handoff.h)
+struct fft_2pass_fused_args {
+    void *data;          // count x n complex, in place
+    void *workspace;     // queues x ring x unit transforms
+    const void *tw_1024; // W_1024^j
+    void *sync;          // fft_2pass_sync_bytes(units, queues) bytes of device memory (zeroed by the launcher)
+    void *sticky = nullptr;  // one word outside that block, or null: set to 1 by a launch that gave up
+    uint64_t spin_limit = 200000000ull; // wall_clock64 ticks (100 MHz) a hand-off poll may take: 2 s; 0 = fault injection
+    uint64_t count;
+    uint32_t n;
+    uint32_t unit;       // transforms per ticket step
+    uint32_t ring, lag;  // ring slots (units) per queue; steps pass 2 trails pass 1 (lag < ring)
+    uint32_t queues;
+    float scale;
+    double scale_d;
+    int reverse;
+};
+size_t fft_2pass_sync_bytes(uint64_t units, uint32_t queues);
+void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *queues, uint32_t *ring, uint32_t *lag);
+int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *stream);
+// sizes whose DEFAULT schedule is the persistent launch (where it measured faster than two launches per chunk)
+bool fft_2pass_fused_preferred(uint32_t n, int precision);
+
 // ------------------------------------------------------------------------------------------
 // IIR bank
 struct iir_args {

@@ -859,6 +859,87 @@ def test_fft1m_lost_handoff_is_reported(sd, torch_cuda):
     assert rel_max_err(y[[0, batch - 1]], want) < TOL32
 
 
+# which variant of a two-pass plan is the persistent launch, which the two launches per chunk (capi.hip: select_kernel)
+def _two_pass_variants(sd, n, prec):
+    probe = sd.FftPlan(n, 2, sd.forward_fft, prec, max_batch=4096)
+    fused = 0 if probe.info.kernel.decode() == "sdsp_fft2p_fused" else 3
+    return fused, 3 - fused
+
+
+@pytest.mark.parametrize("n,precision,batch", [(1 << 16, "f32", 531), (1 << 17, "f32", 300), (1 << 18, "f32", 131), (1 << 19, "f32", 67),
+                                               (1 << 21, "f32", 19), (1 << 22, "f32", 9),
+                                               (1 << 16, "f64", 259), (1 << 17, "f64", 131), (1 << 18, "f64", 67), (1 << 19, "f64", 35), (1 << 20, "f64", 17)])
+def test_two_pass_persistent_schedule(sd, torch_cuda, oracle, n, precision, batch):
+    """fft_2pass.hip: the two passes in ONE persistent, ticketed launch (sdsp_fft2p_fused) do the same arithmetic as the two
+    launches per chunk -> the same bits.  The batches are ragged against the ticket unit (a short last unit), leave the ticket
+    queues uneven and are longer than the ring of intermediates, so slots are re-used within a call; the ring is also re-used
+    across calls.  A few transforms are held to the oracle (numpy above 2^20, where the oracle takes seconds per transform)."""
+    torch = torch_cuda
+    f64 = precision == "f64"
+    prec = sd.F64 if f64 else sd.F32
+    fused, chunked = _two_pass_variants(sd, n, prec)
+    g = torch.Generator(device="cuda").manual_seed(n % 1009 + batch)
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device="cuda", dtype=torch.float64 if f64 else torch.float32))
+    pick = [0, batch // 2, batch - 1]
+    xs = x[pick].cpu().numpy().astype(np.complex128)
+    tol = _tol64(n) if f64 else TOL32
+    for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
+        want = oracle.fft(xs, 2, rev) if n <= (1 << 20) else (np.fft.ifft(xs, axis=-1) if rev else np.fft.fft(xs, axis=-1))
+        plan = sd.FftPlan(n, 2, T, prec, max_batch=batch)
+        plan.set_variant(fused)
+        assert plan.info.kernel.decode() == "sdsp_fft2p_fused" and plan.info.hbm_passes == 2
+        assert plan.launches(batch) == 1
+        first = None
+        for rep in range(2):
+            y = x.clone()
+            plan.exec(y)
+            plan.exec(y.clone())  # a second call right behind it must not disturb the first one's result
+            plan.status()  # synchronises; raises if a bounded wait of the in-kernel hand-off gave up
+            assert rel_max_err(y[pick].cpu().numpy(), want) < tol, (rev, rep)
+            if first is None:
+                first = y
+            else:
+                assert torch.equal(torch.view_as_real(first), torch.view_as_real(y))
+        plan.set_variant(chunked)
+        assert plan.info.kernel.decode() == "sdsp_fft2p_cols+sdsp_fft2p_rows"
+        z = x.clone()
+        plan.exec(z)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(first), torch.view_as_real(z)), rev
+    # a plan made for a batch smaller than the ring of intermediates runs the two launches under either variant number
+    small = sd.FftPlan(n, 2, sd.forward_fft, prec, max_batch=2)
+    for variant in (0, 3):
+        small.set_variant(variant)
+        assert small.info.kernel.decode() == "sdsp_fft2p_cols+sdsp_fft2p_rows"
+
+
+def test_two_pass_lost_handoff_is_reported(sd, torch_cuda):
+    """The persistent two-pass launch shares sdsp_fft1m_fused's bounded waits and sticky abort word (handoff.h): with the wait
+    bound forced to zero every wait gives up; exec_host must return the error, exec leaves it for status(), a healthy call clears it."""
+    torch = torch_cuda
+    n, batch = 1 << 18, 160
+    fused, _ = _two_pass_variants(sd, n, sd.F32)
+    plan = sd.FftPlan(n, 2, sd.forward_fft, sd.F32, max_batch=batch)
+    plan.set_variant(fused)
+    assert plan.info.kernel.decode() == "sdsp_fft2p_fused"
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    plan.set_wait_limit(0)
+    with pytest.raises(sd.SdspHipError) as e:
+        plan.exec_host(x.copy())
+    assert "gave up" in str(e.value)
+    d = torch.from_numpy(x).cuda()
+    plan.exec(d)
+    with pytest.raises(sd.SdspHipError):
+        plan.status()
+    plan.set_wait_limit(200_000_000)
+    y = x.copy()
+    plan.exec_host(y)
+    plan.status()
+    want = np.fft.fft(x[[0, batch - 1]].astype(np.complex128), axis=-1)
+    assert rel_max_err(y[[0, batch - 1]], want) < TOL32
+
+
 def test_bench_under_torch_distributed_run_on_one_gpu(sd, torch_cuda):
     """round 2 verdict, next #8: the N-rank path of bench.py (RCCL process group, throw-away barrier, barrier + max over
     ranks around the timed steps, ONE JSON line from rank 0) runs here as a FRESH child process tree under
