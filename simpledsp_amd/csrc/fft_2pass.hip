@@ -832,13 +832,16 @@ template <int L, int L1, typename C> int launch_dir(const fft_2pass_args &a, hip
 }
 } // namespace
 
-// f32: N = 2^16 .. 2^19 and 2^21, 2^22 (2^20 has the persistent kernel of fft1m.hip); f64: N = 2^16 .. 2^20
+// f32: N = 2^16 .. 2^19 and 2^21, 2^22 (2^20 has the persistent kernel of fft1m.hip); f64: N = 2^15 .. 2^20 (2^15 = 128 x 256: columns of
+// 128 points on FOUR threads each -- one wave per tile; f32 N = 2^15 is a single-pass size, fft_big.hip)
 bool fft_2pass_supports(uint32_t n, int precision)
 {
-    if (!sdsp_hip_is_power_of_2(n) || n < (1u << 16))
+    if (!sdsp_hip_is_power_of_2(n) || n < (1u << 15))
         return false;
     if (precision == SDSP_HIP_F64)
         return n <= (1u << 20);
+    if (n < (1u << 16))
+        return false;
     return n <= (1u << 19) || n == (1u << 21) || n == (1u << 22);
 }
 
@@ -850,6 +853,7 @@ int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (precision == SDSP_HIP_F64) {
         switch (a.n) {
+        case 1u << 15: return launch_dir<15, 7, double2>(a, s);  //  128 x  256
         case 1u << 16: return launch_dir<16, 8, double2>(a, s);  //  256 x  256
         case 1u << 17: return launch_dir<17, 8, double2>(a, s);  //  256 x  512
         case 1u << 18: return launch_dir<18, 9, double2>(a, s);  //  512 x  512
@@ -913,6 +917,7 @@ int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *s
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (precision == SDSP_HIP_F64) {
         switch (a.n) {
+        case 1u << 15: return launch_fused_dir<shape32<15, 7, double2>>(a, s);
         case 1u << 16: return launch_fused_dir<shape32<16, 8, double2>>(a, s);
         case 1u << 17: return launch_fused_dir<shape32<17, 8, double2>>(a, s);
         case 1u << 18: return launch_fused_dir<shape32<18, 9, double2>>(a, s);

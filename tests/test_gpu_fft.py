@@ -309,8 +309,8 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
         fast = None  # round 3: sizes whose default is no longer the three-pass schedule (it became their variant 1)
         if n == 1 << 14:
             fast = ("sdsp_fft_big_f64_kernel", 1)  # the registers-resident kernel in double (radix-2 or radix-4 stages)
-        elif n >= 1 << 16:
-            fast = ("sdsp_fft2p_cols+sdsp_fft2p_rows", 2)  # the two-pass kernels in double
+        elif n >= 1 << 15:
+            fast = ("sdsp_fft2p_cols+sdsp_fft2p_rows", 2)  # the two-pass kernels in double (2^15 = 128 x 256 since the second part of round 3)
         if fast:
             assert plan.info.kernel.decode() == fast[0] and plan.info.hbm_passes == fast[1]
             d0 = torch.from_numpy(x).cuda()
@@ -321,7 +321,7 @@ def test_three_pass_f64(sd, torch_cuda, oracle, n, radix, batch):
         assert plan.info.kernel.decode().startswith("sdsp_fft_col16_kernel")
         # column step + the rows' own passes + untwist.  Rows of 1024 .. 16384 (radix 2) are one pass (N = 16384: the
         # registers-resident kernel in double, were three), rows of 2^15 three, rows of 2^16 two (the two-pass kernels in double)
-        rows_passes = {1 << 14: 1, 1 << 15: 1, 1 << 16: 1, 1 << 17: 1, 1 << 18: 1, 1 << 19: 3, 1 << 20: 2}[n]
+        rows_passes = {1 << 14: 1, 1 << 15: 1, 1 << 16: 1, 1 << 17: 1, 1 << 18: 1, 1 << 19: 2, 1 << 20: 2}[n]
         assert plan.info.hbm_passes == 2 + rows_passes
         d = torch.from_numpy(x).cuda()
         plan.exec(d)
@@ -743,7 +743,7 @@ SIZE_TABLE = [
     (64, 4, "f64", "sdsp_fft_reg_f64_kernel", 1, 4), (1024, 2, "f64", "sdsp_fft_reg_f64_kernel", 1, 2),
     (4096, 4, "f64", "sdsp_fft_big_f64_kernel", 1, 4), (4096, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
     (8192, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2), (16384, 2, "f64", "sdsp_fft_big_f64_kernel", 1, 2),
-    (16384, 4, "f64", "sdsp_fft_big_f64_kernel", 1, 4), (1 << 15, 2, "f64", "sdsp_fft_col16_kernel+rows+sdsp_fft_untwist16", 3, 2),
+    (16384, 4, "f64", "sdsp_fft_big_f64_kernel", 1, 4), (1 << 15, 2, "f64", "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2),
 ]
 
 
@@ -868,7 +868,7 @@ def _two_pass_variants(sd, n, prec):
 
 @pytest.mark.parametrize("n,precision,batch", [(1 << 16, "f32", 531), (1 << 17, "f32", 300), (1 << 18, "f32", 131), (1 << 19, "f32", 67),
                                                (1 << 21, "f32", 19), (1 << 22, "f32", 9),
-                                               (1 << 16, "f64", 259), (1 << 17, "f64", 131), (1 << 18, "f64", 67), (1 << 19, "f64", 35), (1 << 20, "f64", 17)])
+                                               (1 << 15, "f64", 515), (1 << 16, "f64", 259), (1 << 17, "f64", 131), (1 << 18, "f64", 67), (1 << 19, "f64", 35), (1 << 20, "f64", 17)])
 def test_two_pass_persistent_schedule(sd, torch_cuda, oracle, n, precision, batch):
     """fft_2pass.hip: the two passes in ONE persistent, ticketed launch (sdsp_fft2p_fused) do the same arithmetic as the two
     launches per chunk -> the same bits.  The batches are ragged against the ticket unit (a short last unit), leave the ticket

@@ -12,7 +12,7 @@ radix = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 total = 1 << 26  # complex128 elements = 1 GiB
 buf = torch.view_as_complex(torch.randn((total, 2), device="cuda", dtype=torch.float64))
 for rep in range(rounds):
-    for n, variants in ((64, (0,)), (1024, (0,)), (4096, (0, 1)), (8192, (0, 1)), (16384, (0, 1)), (1 << 16, (0,)), (1 << 20, (0,))):
+    for n, variants in ((64, (0,)), (1024, (0,)), (4096, (0, 1)), (8192, (0, 1)), (16384, (0, 1)), (1 << 15, (0, 1, 3)), (1 << 16, (0, 3)), (1 << 20, (0, 3))):
         if radix == 4 and not sd.isPowerOf4(n):
             continue
         batch = total // n
