@@ -121,7 +121,7 @@ int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
  * multi-pass (so sdsp_hip_fft_exec never allocates and can be stream-captured), on first use by an alternate variant
  * otherwise; larger batches are processed in slices of max_batch.  Twiddles are precomputed in double, rounded once to
  * the plan precision and kept resident in HBM.
- * One exec per plan in flight: the multi-pass kernels share the plan's workspace (and the n = 2^20 kernel its ticket
+ * One exec per plan in flight: the multi-pass kernels share the plan's workspace (and the persistent kernels their ticket
  * counters), so two sdsp_hip_fft_exec calls on the SAME plan must not overlap (different streams / host threads): use one
  * plan per stream.  Distinct plans are independent.
  */
@@ -169,12 +169,13 @@ int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int rad
 int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction, int precision,
                                 uint64_t max_batch, int device);
 
-/* Synchronises the plan's device and reports the health of its last sdsp_hip_fft_exec call.  The persistent N = 2^20 kernel
- * hands an intermediate from one workgroup to another inside a launch; every wait of that hand-off is bounded (2 s), and a
+/* Synchronises the plan's device and reports the health of its last sdsp_hip_fft_exec call.  The persistent kernels (n = 2^20
+ * f32: "sdsp_fft1m_fused"; the other two-pass sizes where the plan info names "sdsp_fft2p_fused")
+ * hand an intermediate from one workgroup to another inside a launch; every wait of that hand-off is bounded (2 s), and a
  * wait that gives up marks the call (a sticky word that every launch of the call can set and only the next call clears)
  * instead of hanging the GPU: this returns SDSP_HIP_ERR_HIP then, SDSP_HIP_OK otherwise (always OK for plans whose kernels
  * have no in-kernel hand-off).  The synchronous sdsp_hip_fft_exec_host checks the same word itself and returns the error;
- * ASYNCHRONOUS callers of n = 2^20 plans (sdsp_hip_fft_exec) must call this before trusting the output.  Has no reference
+ * ASYNCHRONOUS callers of such plans (sdsp_hip_fft_exec) must call this before trusting the output.  Has no reference
  * counterpart. */
 int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
 /* Testing hook for the error path above: the bound of the hand-off waits in 100 MHz ticks (default 200 000 000 = 2 s);
@@ -217,8 +218,11 @@ int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out
 /* choose among kernel variants of a plan (tuning/testing).  Variant 0 is the default; a plan has at most two documented
  * alternates (same transform, same tolerance; DESIGN.md section 5 lists them per size: e.g. n = 4096 radix 4: 1, 2 = other
  * store / barrier schedules of the same kernel; n = 8192 AUTO plans and n = 16384 radix-4 plans: 1 = the fft_mix.hip kernel
- * (mixed radix / leading radix-4 stage); n = 2^16 ..
- * 2^19: 1 = three streaming passes; n = 2^20: 1 = two launches per chunk; n = 256 / 1024 / 2048 f32, whose default is a
+ * (mixed radix / leading radix-4 stage); the two-pass sizes (f32 n = 2^16 .. 2^19, 2^21, 2^22; f64 n = 2^15 .. 2^20): 1 = three
+ * streaming passes, 3 = the other SCHEDULE of the same two passes -- one persistent, ticketed launch ("sdsp_fft2p_fused") against two
+ * launches per chunk ("sdsp_fft2p_cols+sdsp_fft2p_rows"), bit-identical results; the default is the one that measured faster for the
+ * size (persistent: f32 2^17 / 2^19 / 2^21 / 2^22, f64 2^18 .. 2^20), and plans whose workspace (max_batch) is smaller than the
+ * persistent launch's 256 MiB ring of intermediates run the two launches under either number; n = 2^20 f32: 1 = two launches per chunk; n = 256 / 1024 / 2048 f32, whose default is a
  * one-wave kernel (fft_wave.hip): 1, 2 = the register-pass family with the default / streaming cache policy -- also for
  * real-input plans of n_real = 512 / 1024 / 2048 and, as variant 2 of sdsp_hip_fft_convolve, for the fused convolution of
  * n = 256 .. 2048; f64 n = 1024: 1 = the one-wave kernel); any larger number selects the untuned coverage kernel
