@@ -119,7 +119,8 @@ int sdsp_hip_calc_twiddles(unsigned n, int direction, double *out);
  * reference's static_asserts).  `max_batch` sizes the plan-owned workspace that transforms too
  * large for on-chip memory need (n > 32768 in f32, n > 16384 in f64): allocated here when the plan's default kernel is
  * multi-pass (so sdsp_hip_fft_exec never allocates and can be stream-captured), on first use by an alternate variant
- * otherwise; larger batches are processed in slices of max_batch.  Twiddles are precomputed in double, rounded once to
+ * otherwise; larger batches are processed in slices of max_batch (the two-pass sizes never hold more than 256 MiB of intermediate:
+ * their workspace stops growing there).  Twiddles are precomputed in double, rounded once to
  * the plan precision and kept resident in HBM.
  * One exec per plan in flight: the multi-pass kernels share the plan's workspace (and the persistent kernels their ticket
  * counters), so two sdsp_hip_fft_exec calls on the SAME plan must not overlap (different streams / host threads): use one

@@ -1002,6 +1002,10 @@ int sdsp_hip_fft_plan_create(sdsp_hip_fft_plan **out, uint32_t n, int radix, int
         pick_tile(precision, p->n2, 16, &p->cols2, &p->pitch2);
         // the tuned 2^20 path keeps 24 intermediates for the persistent kernel (8 queues x 3) / 32 for variant 1's chunks
         p->ws_batch = p->path == PATH_FFT1M ? std::min<uint64_t>(p->max_batch, 32) : p->max_batch;
+        // the two-pass sizes never touch more than 256 MiB of intermediate at a time (a chunk of the two launches, the persistent
+        // launch's ring): their workspace stops there instead of growing with max_batch (the alternates run in slices of it)
+        if (p->path == PATH_FOUR_STEP && fft_2pass_supports(n, precision))
+            p->ws_batch = std::min<uint64_t>(p->max_batch, std::max<uint64_t>(1, (1ull << 28) / ((uint64_t)n * esize(precision))));
         p->workspace_bytes = p->ws_batch * n * esize(precision); // allocated by the first exec that needs it
         if (!rc && p->path == PATH_FFT1M) {
             p->sync_count = std::min<uint64_t>(p->max_batch, kFft1mPerLaunch);

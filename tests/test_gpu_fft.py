@@ -861,7 +861,7 @@ def test_fft1m_lost_handoff_is_reported(sd, torch_cuda):
 
 # which variant of a two-pass plan is the persistent launch, which the two launches per chunk (capi.hip: select_kernel)
 def _two_pass_variants(sd, n, prec):
-    probe = sd.FftPlan(n, 2, sd.forward_fft, prec, max_batch=4096)
+    probe = sd.FftPlan(n, 2, sd.forward_fft, prec, max_batch=max(16, (1 << 28) // (n * (16 if prec == sd.F64 else 8))))
     fused = 0 if probe.info.kernel.decode() == "sdsp_fft2p_fused" else 3
     return fused, 3 - fused
 
