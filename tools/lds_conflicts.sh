@@ -24,6 +24,8 @@ if [ "$1" = "r03" ]; then # round 3's new kernels (old output of gpurun_out/lds/
     run fft1m_f64 --workload fft --n 1048576 --radix 2 --precision f64
     run fft2m --workload fft --n 2097152 --radix 2
     run fft4m --workload fft --n 4194304 --radix 2
+    run fft512k --workload fft --n 524288 --radix 2
+    run fft32768_f64 --workload fft --n 32768 --radix 2 --precision f64
     exit 0
 fi
 run fft4096 --no-other-configs
