@@ -899,12 +899,14 @@ void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *
 //   f64  2^16: 35.4 v 36.2 / 37.9 v 37.1   2^17: 35.7 v 36.2 / 38.0 v 37.0     2^18: 35.5 v 33.8 / 37.9 v 34.6     2^19: 36.0 v 32.6 / 38.0 v 33.7
 //        2^20: 36.4 v 34.1 / 38.2 v 34.3
 // The persistent launch pays per item (two barriers, a drained store queue before the hand-off), which small tiles feel
-// (2^16: 32 KiB items), and a ramp at either end of the batch, which short batches feel.  Default where it won at both sizes.
+// (2^16: 32 KiB items), and a ramp at either end of the batch, which short batches feel.  Sustained (bench.py --workload fft, 100 steps of
+// 1 GiB, tools/ab_two_pass_bench.sh): f32 2^16 30.9 v 38.0, 2^17 40.3 v 37.5, 2^18 40.1 v 37.9; f64 2^15 36.8 v 36.4, 2^16 36.5 v 37.6,
+// 2^17 37.5 v 37.3.  Default where it won both ways.
 bool fft_2pass_fused_preferred(uint32_t n, int precision)
 {
     if (precision == SDSP_HIP_F64)
         return n >= (1u << 18) && n <= (1u << 20);
-    return n == (1u << 17) || n == (1u << 19) || n == (1u << 21) || n == (1u << 22);
+    return n >= (1u << 17); // every f32 two-pass size but 2^16
 }
 
 // both passes over `count` transforms in ONE persistent launch (the workspace holds queues x ring x unit intermediates)
