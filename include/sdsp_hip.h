@@ -221,8 +221,8 @@ int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out
  * store / barrier schedules of the same kernel; n = 8192 AUTO plans and n = 16384 radix-4 plans: 1 = the fft_mix.hip kernel
  * (mixed radix / leading radix-4 stage); the two-pass sizes (f32 n = 2^16 .. 2^19, 2^21, 2^22; f64 n = 2^15 .. 2^20): 1 = three
  * streaming passes, 3 = the other SCHEDULE of the same two passes -- one persistent, ticketed launch ("sdsp_fft2p_fused") against two
- * launches per chunk ("sdsp_fft2p_cols+sdsp_fft2p_rows"), bit-identical results; the default is the one that measured faster for the
- * size (persistent: f32 2^17 .. 2^22, f64 2^18 .. 2^20), and plans whose workspace (max_batch) is smaller than the
+ * launches per chunk ("sdsp_fft2p_cols+sdsp_fft2p_rows"), bit-identical results; the default is the persistent launch (level or faster at
+ * every size, 1 - 5 points of HBM peak), and plans whose workspace (max_batch) is smaller than the
  * persistent launch's 256 MiB ring of intermediates run the two launches under either number; n = 2^20 f32: 1 = two launches per chunk; n = 256 / 1024 / 2048 f32, whose default is a
  * one-wave kernel (fft_wave.hip): 1, 2 = the register-pass family with the default / streaming cache policy -- also for
  * real-input plans of n_real = 512 / 1024 / 2048 and, as variant 2 of sdsp_hip_fft_convolve, for the fused convolution of

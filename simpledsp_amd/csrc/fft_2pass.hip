@@ -600,16 +600,19 @@ __device__ __forceinline__ uint32_t fresh_tid()
     return t;
 }
 // what the persistent kernel needs to know about a size: both passes on 32 points per thread (cols_tile2p / rows_tile2p)
-template <int L_, int L1_, typename C_> struct shape32 {
+// MIN_THREADS: the least workgroup size -- f32 N = 2^16 (two 128-thread passes) takes 256, i.e. two tiles side by side in BOTH passes:
+// half as many items, each as large as N = 2^17's
+template <int L_, int L1_, typename C_, int MIN_THREADS = 64> struct shape32 {
     using C = C_;
     using Real = typename w32<C>::real;
     static constexpr int L = L_, L1 = L1_, L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2;
     static constexpr int THREADS_C = kTile * (N1 / 32), THREADS_R = kTile * (N2 / 32);
-    static constexpr int THREADS = THREADS_C > THREADS_R ? THREADS_C : THREADS_R;
+    static constexpr int THREADS_P = THREADS_C > THREADS_R ? THREADS_C : THREADS_R;
+    static constexpr int THREADS = THREADS_P > MIN_THREADS ? THREADS_P : MIN_THREADS;
     static constexpr int GC = THREADS / THREADS_C, GR = THREADS / THREADS_R; // tiles side by side in one item
     static constexpr int MIN_WAVES = sizeof(Real) == 4 ? 4 : 2; // per SIMD: <= 128 VGPRs in f32 (as the two-launch kernels), <= 256 in double
     static constexpr int ITEMS_C = (N2 / kTile) / GC, ITEMS_R = (N1 / kTile) / GR; // per transform
-    static constexpr size_t PLANE = (size_t)(N1 > N2 ? N1 : N2) * kTile * sizeof(Real);
+    static constexpr size_t PLANE = (size_t)32 * THREADS * sizeof(Real); // G tiles of 32 points per thread, either pass
     // LDS: plane | W_1024 | qtab (pass 1's column twiddles, G tiles).  Pass 2's thread twiddles (1.25 / 2.5 KiB) are rebuilt from
     // the W_1024 copy into the qtab area by every pass-2 item (qtab is dead then; the barrier inside rows_tile2p covers it), and
     // the ticket mailbox lies over the plane's first 16 bytes -- the plane is dead between items, a tile function's own barrier
@@ -902,11 +905,12 @@ void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *
 // (2^16: 32 KiB items), and a ramp at either end of the batch, which short batches feel.  Sustained (bench.py --workload fft, 100 steps of
 // 1 GiB, tools/ab_two_pass_bench.sh): f32 2^16 30.9 v 38.0, 2^17 40.3 v 37.5, 2^18 40.1 v 37.9; f64 2^15 36.8 v 36.4, 2^16 36.5 v 37.6,
 // 2^17 37.5 v 37.3.  Default where it won both ways.
+// Since the small-tile sizes run two tiles side by side in both passes (MIN_THREADS = 256: f32 2^16 40.0 v 38.4, f64 2^15 38.5 v 36.8,
+// f64 2^16 38.3 v 37.7 sustained) the persistent launch is at least level at every size: it is every two-pass plan's default.
 bool fft_2pass_fused_preferred(uint32_t n, int precision)
 {
-    if (precision == SDSP_HIP_F64)
-        return n >= (1u << 18) && n <= (1u << 20);
-    return n >= (1u << 17); // every f32 two-pass size but 2^16
+    (void)precision;
+    return n != 0;
 }
 
 // both passes over `count` transforms in ONE persistent launch (the workspace holds queues x ring x unit intermediates)
@@ -919,8 +923,8 @@ int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *s
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (precision == SDSP_HIP_F64) {
         switch (a.n) {
-        case 1u << 15: return launch_fused_dir<shape32<15, 7, double2>>(a, s);
-        case 1u << 16: return launch_fused_dir<shape32<16, 8, double2>>(a, s);
+        case 1u << 15: return launch_fused_dir<shape32<15, 7, double2, 256>>(a, s);
+        case 1u << 16: return launch_fused_dir<shape32<16, 8, double2, 256>>(a, s);
         case 1u << 17: return launch_fused_dir<shape32<17, 8, double2>>(a, s);
         case 1u << 18: return launch_fused_dir<shape32<18, 9, double2>>(a, s);
         case 1u << 19: return launch_fused_dir<shape32<19, 9, double2>>(a, s);
@@ -930,7 +934,7 @@ int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *s
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "size not covered by the two-pass kernels");
     }
     switch (a.n) {
-    case 1u << 16: return launch_fused_dir<shape32<16, 8, float2>>(a, s);
+    case 1u << 16: return launch_fused_dir<shape32<16, 8, float2, 256>>(a, s);
     case 1u << 17: return launch_fused_dir<shape32<17, 8, float2>>(a, s);
     case 1u << 18: return launch_fused_dir<shape32<18, 9, float2>>(a, s);
     case 1u << 19: return launch_fused_dir<shape32<19, 9, float2>>(a, s);
