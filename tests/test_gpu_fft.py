@@ -825,6 +825,9 @@ def test_launch_count_query(sd, torch_cuda):
         assert sd.FftPlan(16384, 2, sd.forward_fft, sd.F32, max_batch=16).launches(1 << 14) == 1  # never in pieces
         assert sd.FftPlan(1 << 20, 2, sd.forward_fft, sd.F32, max_batch=256).launches(256) == 1
         p2 = sd.FftPlan(1 << 16, 2, sd.forward_fft, sd.F32, max_batch=2048)
+        assert p2.launches(2048) == 1  # the persistent two-pass launch (one per 1024 units of 8 MiB)
+        assert p2.launches(2049) == 2 and p2.launches(4097) == 3  # max_batch = 2048 sized the counters: 128 units of 16 per launch
+        p2.set_variant(3)
         assert p2.launches(2048) == 2 * 4  # chunks of 2^25 / n = 512 transforms, two passes each
         sd.set_launch_piece_bytes(0)
         assert p.launches(262144) == 1
