@@ -496,13 +496,17 @@ def main():
     # each; no CPU leg), reported compactly
     extras = []
     if world == 1 and args.workload == "fft4096" and args.extras and not args.no_extras and not args.batch_per_gpu and args.variant < 0:
-        keep_n, keep_radix = args.n, args.radix
-        for name, n, radix in (("fft", 8192, 0), ("fft", 16384, 2), ("fft", 16384, 4), ("fft", 32768, 2), ("conv", 4096, 4), ("conv", 8192, 2),
-                               ("conv", 16384, 2), ("rfft", 16384, 2), ("rfft", 32768, 2)):
-            args.n, args.radix = n, radix
+        keep_n, keep_radix, keep_prec = args.n, args.radix, args.precision
+        for name, n, radix, prec in (("fft", 8192, 0, "f32"), ("fft", 16384, 2, "f32"), ("fft", 16384, 4, "f32"), ("fft", 32768, 2, "f32"),
+                                     ("conv", 4096, 4, "f32"), ("conv", 8192, 2, "f32"), ("conv", 16384, 2, "f32"), ("rfft", 16384, 2, "f32"),
+                                     ("rfft", 32768, 2, "f32"),
+                                     # two passes over HBM in one persistent launch (fft_2pass.hip), and the f64 single-pass sizes
+                                     ("fft", 1 << 16, 2, "f32"), ("fft", 1 << 19, 2, "f32"), ("fft", 1 << 21, 2, "f32"), ("fft", 1 << 22, 2, "f32"),
+                                     ("fft", 8192, 2, "f64"), ("fft", 16384, 2, "f64"), ("fft", 1 << 15, 2, "f64"), ("fft", 1 << 20, 2, "f64")):
+            args.n, args.radix, args.precision = n, radix, prec
             r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
-            extras.append({"what": f"{name} n={n} radix={radix}", **compact(r)})
-        args.n, args.radix = keep_n, keep_radix
+            extras.append({"what": f"{name} n={n} radix={radix}" + (" f64" if prec == "f64" else ""), **compact(r)})
+        args.n, args.radix, args.precision = keep_n, keep_radix, keep_prec
 
     if rank == 0:
         out = {
