@@ -448,12 +448,10 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
     }
     const bool two_pass_size = fft_2pass_supports(p->n, p->precision);
     // two schedules over the same tiles (bit-identical results): ONE persistent, ticketed launch (the workspace is a ring of
-    // intermediates inside the Infinity Cache; needs a plan whose workspace holds that ring) and two launches per chunk of
-    // 256 MiB.  Variant 0 is the one that measured faster at 1 AND 2 GiB batches in one call (profiles/r03_fft2p_fused_lab.txt),
-    // variant 3 the other
+    // intermediates inside the Infinity Cache; needs a plan whose workspace holds that ring) -- variant 0, level or ahead at every size in
+    // one-call A/Bs (fft_2pass.hip, profiles/r03_fft2p_fused_lab.txt) -- and two launches per chunk of 256 MiB, variant 3
     if (p->path == PATH_FOUR_STEP && two_pass_size && (variant == 0 || variant == 3)) {
-        const bool fused_first = fft_2pass_fused_preferred(p->n, p->precision);
-        if (p->f2_unit && (variant == 0) == fused_first)
+        if (p->f2_unit && variant == 0)
             return { K_2PASS_FUSED, "sdsp_fft2p_fused", 2, 2, true, false };
         return { K_2PASS, "sdsp_fft2p_cols+sdsp_fft2p_rows", 2, 2, true, false };
     }

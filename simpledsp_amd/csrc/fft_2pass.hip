@@ -904,14 +904,10 @@ void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *
 // The persistent launch pays per item (two barriers, a drained store queue before the hand-off), which small tiles feel
 // (2^16: 32 KiB items), and a ramp at either end of the batch, which short batches feel.  Sustained (bench.py --workload fft, 100 steps of
 // 1 GiB, tools/ab_two_pass_bench.sh): f32 2^16 30.9 v 38.0, 2^17 40.3 v 37.5, 2^18 40.1 v 37.9; f64 2^15 36.8 v 36.4, 2^16 36.5 v 37.6,
-// 2^17 37.5 v 37.3.  Default where it won both ways.
+// 2^17 37.5 v 37.3.
 // Since the small-tile sizes run two tiles side by side in both passes (MIN_THREADS = 256: f32 2^16 40.0 v 38.4, f64 2^15 38.5 v 36.8,
-// f64 2^16 38.3 v 37.7 sustained) the persistent launch is at least level at every size: it is every two-pass plan's default.
-bool fft_2pass_fused_preferred(uint32_t n, int precision)
-{
-    (void)precision;
-    return n != 0;
-}
+// f64 2^16 38.3 v 37.7 sustained) the persistent launch is at least level at every size: it is every two-pass plan's default
+// (capi.hip: select_kernel; the two launches per chunk are variant 3).
 
 // both passes over `count` transforms in ONE persistent launch (the workspace holds queues x ring x unit intermediates)
 int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *stream)

@@ -188,8 +188,6 @@ struct fft_2pass_fused_args {
 size_t fft_2pass_sync_bytes(uint64_t units, uint32_t queues);
 void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *queues, uint32_t *ring, uint32_t *lag);
 int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *stream);
-// sizes whose DEFAULT schedule is the persistent launch (where it measured faster than two launches per chunk)
-bool fft_2pass_fused_preferred(uint32_t n, int precision);
 
 // ------------------------------------------------------------------------------------------
 // IIR bank
