@@ -446,6 +446,10 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
             return { K_FFT1M_CHUNKED, "sdsp_fft1m_cols+sdsp_fft1m_rows", 2, 2, true, false };
         return { K_FFT1M_FUSED, "sdsp_fft1m_fused", 2, 2, true, false };
     }
+    // variant 2: the same schedule through fft_2pass.hip's generic persistent kernel (its tile functions at 1024 x 1024) -- the A/B that
+    // says what the dedicated kernel of fft1m_kernels.h is worth
+    if (p->path == PATH_FFT1M && variant == 2 && p->ws_batch >= 4 * kFft1mQueues)
+        return { K_2PASS_FUSED, "sdsp_fft2p_fused", 2, 2, true, false };
     const bool two_pass_size = fft_2pass_supports(p->n, p->precision);
     // two schedules over the same tiles (bit-identical results): ONE persistent, ticketed launch (the workspace is a ring of
     // intermediates inside the Infinity Cache; needs a plan whose workspace holds that ring) -- variant 0, level or ahead at every size in
@@ -641,21 +645,22 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
 
     // the two-pass sizes in one persistent launch per kFused2pUnitsPerLaunch units
     if (sel.id == K_2PASS_FUSED) {
-        const uint64_t per_launch = p->sync_count * p->f2_unit;
+        const bool m1 = p->path == PATH_FFT1M; // unit = one transform, the counters of the dedicated kernel
+        const uint64_t per_launch = m1 ? p->sync_count : p->sync_count * p->f2_unit;
         for (uint64_t done = 0; done < batch; done += per_launch) {
             fft_2pass_fused_args a;
             a.data = reinterpret_cast<char *>(data) + done * p->n * esize(p->precision);
             a.workspace = p->workspace;
-            a.tw_1024 = p->tw1024;
+            a.tw_1024 = p->path == PATH_FFT1M ? p->tw1 : p->tw1024; // N = 2^20: n1 = 1024, so W_n1 is that table
             a.sync = p->sync;
             a.sticky = reinterpret_cast<char *>(p->sync) + p->sticky_off;
             a.spin_limit = p->wait_limit;
             a.count = std::min<uint64_t>(per_launch, batch - done);
             a.n = p->n;
-            a.unit = p->f2_unit;
-            a.ring = p->f2_ring;
-            a.lag = p->f2_lag;
-            a.queues = p->f2_queues;
+            a.unit = m1 ? 1 : p->f2_unit;
+            a.ring = m1 ? 4 : p->f2_ring;
+            a.lag = m1 ? 2 : p->f2_lag;
+            a.queues = m1 ? (uint32_t)kFft1mQueues : p->f2_queues;
             a.scale = (float)(1.0 / p->n);
             a.scale_d = 1.0 / p->n;
             a.reverse = rev;
@@ -804,7 +809,7 @@ uint64_t fft_launch_count(const sdsp_hip_fft_plan *p, uint64_t batch, int varian
     case K_FFT1M_CHUNKED: return 2 * ceil_div(batch, fft1m_chunk(p));
     case K_FFT1M_FUSED: return ceil_div(batch, p->sync_count);
     case K_2PASS: return 2 * ceil_div(batch, fft2p_chunk(p));
-    case K_2PASS_FUSED: return ceil_div(batch, p->sync_count * p->f2_unit);
+    case K_2PASS_FUSED: return ceil_div(batch, p->path == PATH_FFT1M ? p->sync_count : p->sync_count * p->f2_unit);
     case K_FOUR_STEP: return 2 * ceil_div(batch, p->ws_batch);
     case K_MID: {
         uint64_t n = 0;

@@ -934,6 +934,7 @@ int launch_fft_2pass_fused(int precision, const fft_2pass_fused_args &a, void *s
     case 1u << 17: return launch_fused_dir<shape32<17, 8, float2>>(a, s);
     case 1u << 18: return launch_fused_dir<shape32<18, 9, float2>>(a, s);
     case 1u << 19: return launch_fused_dir<shape32<19, 9, float2>>(a, s);
+    case 1u << 20: return launch_fused_dir<shape32<20, 10, float2>>(a, s); // (variant 2 of the N = 2^20 plans; their default: fft1m.hip)
     case 1u << 21: return launch_fused_dir<shape64<21>>(a, s);
     case 1u << 22: return launch_fused_dir<shape64<22>>(a, s);
     default: break;

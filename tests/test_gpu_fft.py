@@ -434,6 +434,14 @@ def test_fft1m_schedules_agree(sd, torch_cuda, oracle):
                 first = y
             else:
                 assert torch.equal(first, y), (variant, rep)
+    # variant 2: the same schedule through fft_2pass.hip's generic persistent kernel (other tile functions: same tolerance, not the same bits)
+    plan.set_variant(2)
+    assert plan.info.kernel.decode() == "sdsp_fft2p_fused" and plan.launches(batch) == 1
+    y = x.clone()
+    plan.exec(y)
+    plan.status()
+    assert rel_max_err(y[[0, 17, 36]].cpu().numpy(), want) < TOL32
+    assert rel_max_err(y.cpu().numpy(), first.cpu().numpy().astype(np.complex128)) < TOL32
 
 
 @pytest.mark.parametrize("n,radix,precision,batch", [(4096, 4, "f32", 1), (4096, 4, "f32", 67), (4096, 2, "f32", 5),
