@@ -30,7 +30,8 @@ for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20, 1 <
         x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
         errs = []
         for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
-            plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=batch)
+            # two-pass sizes: a workspace large enough for their default schedule, the persistent launch (a 256 MiB ring of intermediates)
+            plan = sd.FftPlan(n, radix, T, sd.F32, max_batch=max(batch, (1 << 28) // (8 * n)))
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
             torch.cuda.synchronize()
@@ -40,7 +41,7 @@ for n in (16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 20, 1 <
         print(f"| `{plan.info.kernel.decode()}` | N = {n}, radix {radix}, fwd / rev | {errs[0]:.2e} / {errs[1]:.2e} | 1e-6 |")
 
 # double precision (round 3): against the oracle in units of the reference's own bound 4 N eps (testFFT.cpp:37)
-for n in (64, 1024, 4096, 8192, 16384, 1 << 16, 1 << 18, 1 << 20):
+for n in (64, 1024, 4096, 8192, 16384, 1 << 15, 1 << 16, 1 << 18, 1 << 20):
     for radix in (2, 4):
         if radix == 4 and not sd.isPowerOf4(n):
             continue
@@ -48,7 +49,7 @@ for n in (64, 1024, 4096, 8192, 16384, 1 << 16, 1 << 18, 1 << 20):
         x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
         errs = []
         for T, rev in ((sd.forward_fft, False), (sd.reverse_fft, True)):
-            plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=batch)
+            plan = sd.FftPlan(n, radix, T, sd.F64, max_batch=max(batch, (1 << 28) // (16 * n)))
             d = torch.from_numpy(x).cuda()
             plan.exec(d)
             torch.cuda.synchronize()
