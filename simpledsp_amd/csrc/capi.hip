@@ -1295,7 +1295,25 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
         }
         return launch_fft_reg_f32(a, stream);
     }
-    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && p->variant == 0 && !p->real_mode) { // f64, N = 16 .. 8192
+    // double, N = 4096 / 8192 / 16384 radix-2 plans: both transforms and the multiply in the registers-resident kernel (fft_big64.hip);
+    // variant 2: what served N <= 8192 before (the register-pass family's fused MODE 3), any other variant: three launches
+    if ((p->path == PATH_REG || p->path == PATH_FOUR_STEP) && p->precision == SDSP_HIP_F64 && p->variant == 0 && !p->real_mode && p->twt_big &&
+        fft_big64_conv_supports(p->n, p->radix)) {
+        fft_reg_args a;
+        a.data = data;
+        a.tw = p->twt_big;
+        a.n = p->n;
+        a.radix = p->radix;
+        a.batch = batch;
+        a.scale = 1.0f;
+        a.scale_d = 1.0 / p->n;
+        a.reverse = 0;
+        a.nontemporal = 1;
+        a.real_mode = 3;
+        a.tw2 = h;
+        return launch_fft_big_f64(a, stream);
+    }
+    if (p->path == PATH_REG && p->precision == SDSP_HIP_F64 && (p->variant == 0 || p->variant == 2) && !p->real_mode) { // f64, N = 16 .. 8192
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_reg;

@@ -67,29 +67,18 @@ template <int R> __device__ __forceinline__ constexpr uint32_t rot5(uint32_t k)
     return ((k & ((1u << (5 - R)) - 1)) << R) | ((k >> (5 - R)) & ((1u << R) - 1));
 }
 
-template <int L, bool REV, bool NT, bool R4 = false>
-__global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(double2 *__restrict__ data, const double2 *__restrict__ tw,
-                                                                           double scale, uint64_t batch)
+// the transform of one workgroup on registers: in x[k] = element t + T k, out x[i] = X[t + T bit_reverse5(i)] (position 32 w + i of the
+// bit-reversed order, w = bit_reverse(t)).  REV: the direction of the constants; CONJ: the table holds the other direction's thread
+// twiddles (the fused convolution runs its reverse transform on the forward plan's table).  The caller owns the barrier in front of a
+// SECOND transform of the same workgroup (the first one's last plane is still being read)
+template <int L, bool REV, bool R4, bool CONJ>
+__device__ __forceinline__ void big64_transform(double2 (&x)[32], const double2 *__restrict__ tw, uint32_t t)
 {
     constexpr int R = L - 10;
-    static_assert(R >= 2 && R <= 4, "N = 4096 / 8192 / 16384");
     constexpr uint32_t N = 1u << L, T = N / 32, M = N / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big64_smem[]; // N doubles: one plane of the transform
     auto lds_f64 = [&](uint32_t byte) -> double & { return *reinterpret_cast<double *>(sdsp_fft_big64_smem + byte); };
-
-    const uint32_t t = threadIdx.x;
-    const uint32_t toff = t * 16u;
-    const uint64_t xform = blockIdx.x;
-    if (xform >= batch)
-        return;
-    static_assert(!R4 || L == 14 || L == 12, "radix-4 stages: N = 16384 = 4^7 and N = 4096 = 4^6");
-    const __amdgpu_buffer_rsrc_t rows = make_rows64(data + xform * N, N * sizeof(double2));
-
-    double2 x[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++)
-        x[k] = row_load64<NT>(rows, toff, T * k * sizeof(double2));
-
+    static_assert(!(R4 && CONJ), "the convolution form runs radix-2 stages");
     // LDS byte addresses of the three access patterns: fft_big.hip's, with 8-byte slots
     //   pattern A  position k*M + t          ->  8*k*M + (8t ^ 8*rot(k))                  rot(k) is a literal
     //   pattern B  position pb + (j << R)    ->  baseB[j mod 2^(5-R)] + 256*(j >> (5-R))   no arithmetic per access
@@ -124,7 +113,7 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
             x[k] = double2{ upper ? r.x : x[k].x, upper ? r.y : x[k].y };
         }
     } else {
-        fft32_dif<REV, true, 0, true>(x, tw + t, T); // pass A: tw = [pass][stage][thread]
+        fft32_dif<REV, true, 0, true, CONJ>(x, tw + t, T); // pass A: tw = [pass][stage][thread]
     }
 
     // ---- exchange A -> B, one plane at a time
@@ -160,7 +149,7 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
             thr[q] = tab(11 + q);
         r4_stage<REV, 1, 0, 0, true>(x, thr); // stage 4: register bits 1, 0; thread twiddles only
     } else {
-        fft32_dif<REV, true, 0, true>(x, tw + 5 * T + t, T); // pass B
+        fft32_dif<REV, true, 0, true, CONJ>(x, tw + 5 * T + t, T); // pass B
     }
 
     // ---- exchange B -> C
@@ -194,6 +183,31 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
         fft32_dif<REV, false, 5 - R>(x, tw, 0); // pass C: constants only
     }
 
+}
+
+template <int L, bool REV, bool NT, bool R4 = false>
+__global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(double2 *__restrict__ data, const double2 *__restrict__ tw,
+                                                                           double scale, uint64_t batch)
+{
+    constexpr int R = L - 10;
+    static_assert(R >= 2 && R <= 4, "N = 4096 / 8192 / 16384");
+    constexpr uint32_t N = 1u << L, T = N / 32;
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t toff = t * 16u;
+    const uint64_t xform = blockIdx.x;
+    if (xform >= batch)
+        return;
+    static_assert(!R4 || L == 14 || L == 12, "radix-4 stages: N = 16384 = 4^7 and N = 4096 = 4^6");
+    const __amdgpu_buffer_rsrc_t rows = make_rows64(data + xform * N, N * sizeof(double2));
+
+    double2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = row_load64<NT>(rows, toff, T * k * sizeof(double2));
+
+    big64_transform<L, REV, R4, false>(x, tw, t);
+
     // ---- store: position 32w + i holds X[bit_reverse_L(32w + i)] = X[t + T * bit_reverse5(i)]
 #pragma unroll
     for (int i = 0; i < 32; i++) {
@@ -202,6 +216,46 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_kernel(doub
             o.x *= scale;
             o.y *= scale;
         }
+        row_store64<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(double2), o);
+    }
+}
+
+
+// Fused fast convolution data <- IFFT(FFT(data) .* h) in double, N = 4096 / 8192 / 16384, radix-2 stages: the forward
+// transform leaves register i holding X[t + T bit_reverse5(i)]; multiplied by H there (H rows through a buffer resource, default
+// cache policy: every workgroup reads the same N values) and RENAMED z[bit_reverse5(i)] = x[i] -- no data moves -- that is the
+// reverse transform's input layout, which runs on the same registers and LDS plane with the forward plan's table conjugated.
+template <int L, bool NT>
+__global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_conv_kernel(double2 *__restrict__ data, const double2 *__restrict__ tw,
+                                                                                const double2 *__restrict__ h, double scale, uint64_t batch)
+{
+    constexpr uint32_t N = 1u << L, T = N / 32;
+    const uint32_t t = threadIdx.x;
+    const uint32_t toff = t * 16u;
+    const uint64_t xform = blockIdx.x;
+    if (xform >= batch)
+        return;
+    const __amdgpu_buffer_rsrc_t rows = make_rows64(data + xform * N, N * sizeof(double2));
+    const __amdgpu_buffer_rsrc_t rows_h = make_rows64(h, N * sizeof(double2));
+    double2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = row_load64<NT>(rows, toff, T * k * sizeof(double2));
+    big64_transform<L, false, false, false>(x, tw, t);
+    double2 z[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        constexpr uint32_t es = sizeof(double2);
+        const uint32_t r = __brev((uint32_t)i) >> 27;
+        z[r] = cmul(x[i], row_load64<false>(rows_h, toff, T * r * es));
+    }
+    __syncthreads(); // every wave has read the forward transform's last plane
+    big64_transform<L, true, false, true>(z, tw, t);
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        double2 o = z[i];
+        o.x *= scale; // reverse_fft::ScaleValues, fft.h:128-132
+        o.y *= scale;
         row_store64<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(double2), o);
     }
 }
@@ -224,7 +278,29 @@ template <int L, bool REV, bool R4 = false> int launch_l(const fft_reg_args &a, 
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big64 launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
+
+template <int L> int launch_conv_l(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr size_t lds = sizeof(double) << L;
+    auto kern = sdsp_fft_big_f64_conv_kernel<L, true>;
+    if constexpr (lds > 64 * 1024) {
+        static std::atomic<uint64_t> attr_done{ 0 };
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
+            return rc;
+    }
+    if (a.batch > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((uint32_t)a.batch), dim3((1u << L) / 32), lds, s, reinterpret_cast<double2 *>(a.data),
+                       reinterpret_cast<const double2 *>(a.tw), reinterpret_cast<const double2 *>(a.tw2), a.scale_d, a.batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_big64 convolution launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 } // namespace
+
+// the fused convolution in double runs radix-2 stages (a radix-2 plan's table): N = 4096 / 8192 / 16384
+bool fft_big64_conv_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384); }
 
 bool fft_big64_supports(uint32_t n, int radix)
 {
@@ -238,6 +314,14 @@ int launch_fft_big_f64(const fft_reg_args &a, void *stream)
     if (a.batch == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a.real_mode == 3) { // fused convolution: h travels in tw2
+        switch (a.radix == 2 ? a.n : 0u) {
+        case 4096: return launch_conv_l<12>(a, s);
+        case 8192: return launch_conv_l<13>(a, s);
+        case 16384: return launch_conv_l<14>(a, s);
+        default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "fused convolution in double: radix-2 plans of N = 4096 / 8192 / 16384");
+        }
+    }
     if (a.radix == 4) { // a.tw: the radix-4 thread-twiddle table in double
         if (a.n == 4096)
             return a.reverse ? launch_l<12, true, true>(a, s) : launch_l<12, false, true>(a, s);

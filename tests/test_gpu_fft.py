@@ -450,7 +450,8 @@ def test_fft1m_schedules_agree(sd, torch_cuda, oracle):
                                                      (256, 2, "f32", 1027), (256, 4, "f32", 1026), (512, 2, "f32", 77), (2048, 2, "f32", 35),
                                                      (2048, 2, "f32", 3), (16384, 4, "f32", 2), (8192, 2, "f32", 2), (8192, 2, "f32", 37),
                                                      (16384, 2, "f32", 5), (16384, 4, "f32", 7), (1 << 15, 2, "f32", 9),
-                                                     (64, 4, "f64", 70), (4096, 4, "f64", 3), (8192, 2, "f64", 2), (16384, 2, "f64", 2)])
+                                                     (64, 4, "f64", 70), (4096, 4, "f64", 3), (8192, 2, "f64", 2), (16384, 2, "f64", 2),
+                                                     (4096, 2, "f64", 5), (8192, 2, "f64", 37), (16384, 2, "f64", 19)])
 def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, n, radix, precision, batch):
     """x <- IFFT(FFT(x) .* H).  Checker: the reference's own composition
     fft_radix<forward>(x); x *= H; fft_radix<reverse_fft>(x) through the oracle, in double."""
@@ -465,10 +466,12 @@ def test_fast_convolution_matches_reference_composition(sd, torch_cuda, oracle, 
     plan = sd.FftPlan(n, radix, sd.forward_fft, prec, max_batch=batch)
     tol = 2e-6 if prec == sd.F32 else 8 * n * EPS64  # two transforms and a product
     outs = []
-    fused = n <= (16384 if prec == sd.F32 else 8192) or (prec == sd.F32 and radix == 2 and n == 1 << 15)
+    fused = n <= (16384 if prec == sd.F32 else 8192) or (radix == 2 and n == (1 << 15 if prec == sd.F32 else 16384))
     # two fused forms: the one-wave kernel, or (radix 2, N = 8192 / 16384) the registers-resident kernel of csrc/fft_big.hip, + the
     # register-pass MODE 3 as variant 2
-    two_fused = prec == sd.F32 and (n in (256, 1024, 16384) or (radix == 2 and n in (512, 2048, 4096, 8192)))
+    # (double, radix 2, N = 4096 / 8192 / 16384: csrc/fft_big64.hip's convolution form; MODE 3 of the f64 register-pass family = variant 2 up to 8192)
+    two_fused = (prec == sd.F32 and (n in (256, 1024, 16384) or (radix == 2 and n in (512, 2048, 4096, 8192)))) or \
+                (prec == sd.F64 and radix == 2 and n in (4096, 8192))
     for variant in ((0, 1, 2) if two_fused else (0, 1) if fused else (0,)):
         plan.set_variant(variant)  # f32 n <= 16384 (radix 2: 32768), f64 n <= 8192: 0 = fused single kernel, 1 = three launches
         d, hd = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
