@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft1m", "iir", "iir64", "iir_lp", "iir_mix", "iir_il", "fft", "fir", "conv", "rfft"])
     ap.add_argument("--n", type=int, default=1024, help="--workload fft / conv: transform size; rfft: n_real")
     ap.add_argument("--radix", type=int, default=2, help="--workload fft: 2 or 4")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / fir")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="--workload fft / conv / fir")
     ap.add_argument("--taps", type=int, default=32, help="--workload fir: filter length")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the per-GPU unit count")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
@@ -158,25 +158,28 @@ def make_fft(sd, torch, dev, args):
 def make_conv(sd, torch, dev, args):
     """fused fast convolution data <- IFFT(FFT(data) .* h), SURVEY 8(f)-1 (not a BASELINE config): 1 GiB of transforms;
     |h[k]| = 1 (random phases) keeps the in-place data finite over any number of steps"""
-    n = args.n
-    batch = args.batch_per_gpu or max(1, (1 << 27) // n)
+    n, f64 = args.n, args.precision == "f64"
+    batch = args.batch_per_gpu or max(1, (1 << (26 if f64 else 27)) // n)
+    rdt = torch.float64 if f64 else torch.float32
     g = torch.Generator(device=dev).manual_seed(0x5D5B + 6 + dev.index)
-    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device=dev))
-    ph = torch.rand((n,), generator=g, device=dev) * 6.283185307179586
+    x = torch.view_as_complex(torch.randn((batch, n, 2), generator=g, device=dev, dtype=rdt))
+    ph = torch.rand((n,), generator=g, device=dev, dtype=rdt) * 6.283185307179586
     h = torch.polar(torch.ones_like(ph), ph)
-    plan = sd.FftPlan(n, args.radix, sd.forward_fft, sd.F32, max_batch=batch, device=dev.index)
+    plan = sd.FftPlan(n, args.radix, sd.forward_fft, sd.F64 if f64 else sd.F32, max_batch=batch, device=dev.index)
+    if args.variant >= 0:
+        plan.set_variant(args.variant)
 
     def step():
         plan.convolve(x, h)
 
     info = plan.info
     desc = {
-        "workload": f"fused fast convolution N={n} radix-{args.radix} (forward, multiply, reverse in one kernel), in place, f32 "
+        "workload": f"fused fast convolution N={n} radix-{args.radix} (forward, multiply, reverse in one kernel), in place, {args.precision} "
                     "(SURVEY 8(f)-1, not a BASELINE config)",
         "n": n, "radix": args.radix, "batch_per_gpu": batch, "kernel": "fused convolution of " + info.kernel.decode(), "hbm_passes": 1,
     }
-    return (step, batch, int(info.algorithmic_bytes), desc, f"fast convolutions/sec (N={n}, radix-{args.radix}, f32)", "convolutions/s",
-            "f32", (plan, x, h))
+    return (step, batch, int(info.algorithmic_bytes), desc, f"fast convolutions/sec (N={n}, radix-{args.radix}, {args.precision})",
+            "convolutions/s", args.precision, (plan, x, h))
 
 
 def make_rfft(sd, torch, dev, args):
@@ -502,7 +505,8 @@ def main():
                                      ("rfft", 32768, 2, "f32"),
                                      # two passes over HBM in one persistent launch (fft_2pass.hip), and the f64 single-pass sizes
                                      ("fft", 1 << 16, 2, "f32"), ("fft", 1 << 19, 2, "f32"), ("fft", 1 << 21, 2, "f32"), ("fft", 1 << 22, 2, "f32"),
-                                     ("fft", 8192, 2, "f64"), ("fft", 16384, 2, "f64"), ("fft", 1 << 15, 2, "f64"), ("fft", 1 << 20, 2, "f64")):
+                                     ("fft", 8192, 2, "f64"), ("fft", 16384, 2, "f64"), ("fft", 1 << 15, 2, "f64"), ("fft", 1 << 20, 2, "f64"),
+                                     ("conv", 8192, 2, "f64"), ("conv", 16384, 2, "f64")):
             args.n, args.radix, args.precision = n, radix, prec
             r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
             extras.append({"what": f"{name} n={n} radix={radix}" + (" f64" if prec == "f64" else ""), **compact(r)})
