@@ -212,7 +212,7 @@ private:
 
 // real-input packing: n_real real samples <-> packed half spectrum (n_real/2 complex,
 // element 0 = (X[0], X[n_real/2])), in place, half the bytes of the complex transform.  real_t = float
-// (n_real = 32 .. 32768; radix 2: .. 65536) or double (32 .. 16384: the reference's precision).
+// (n_real = 32 .. 32768; radix 2: .. 65536) or double (32 .. 16384; radix 2: .. 32768 -- the reference's precision).
 template <typename real_t> class rfft_plan_t {
 public:
     rfft_plan_t(std::uint32_t n_real, int radix = 2, int direction = SDSP_HIP_FORWARD, std::uint64_t max_batch = 1, int device = 0)

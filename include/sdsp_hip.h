@@ -165,7 +165,7 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *plan, void *data, const void *h, ui
  */
 int sdsp_hip_rfft_plan_create(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction,
                               uint64_t max_batch, int device);
-/* the same with a precision: SDSP_HIP_F64 packs n_real doubles <-> n_real/2 complex doubles (n_real = 32 .. 16384); the
+/* the same with a precision: SDSP_HIP_F64 packs n_real doubles <-> n_real/2 complex doubles (n_real = 32 .. 16384; radix 2: .. 32768); the
  * reference computes in double (fft.h:51-52). */
 int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int radix, int direction, int precision,
                                 uint64_t max_batch, int device);

@@ -360,6 +360,7 @@ enum fft_kernel_id {
     K_BIG,           // fft_big.hip: transform in registers, N = 8192 .. 32768
     K_BIG_REAL,      // fft_big.hip, REAL form (real-input plans, n = n_real / 2 = 2048 .. 32768)
     K_BIG64,         // fft_big64.hip: the same design in double, N = 4096 .. 16384
+    K_BIG64_REAL,    // fft_big64.hip, REAL form (real-input plans in double, n = n_real / 2 = 4096 .. 16384)
     K_REG64,         // fft_reg64.hip: register-pass family in double
     K_WAVE64,        // fft_wave.hip: N = 1024 in double, one transform per two waves
     K_WAVE1024,      // fft_wave.hip: N = 1024 f32, one transform per wave
@@ -416,8 +417,13 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
     const bool big64 = !f32 && !p->real_mode && p->twt_big && fft_big64_supports(p->n, p->radix);
     if (big64 && variant == big64_variant(p->n))
         return { K_BIG64, "sdsp_fft_big_f64_kernel", 1, p->radix == 4 ? 4 : 2, false, pc && p->n <= 4096 };
-    if (p->path == PATH_REG && !f32) {
-        if (big64 && big64_variant(p->n) == 0) // the kernel that was the default becomes variant 1
+    // real-input plans in double of n_real = 8192 / 16384 / 32768 (radix 2): split / merge around the same transform (its REAL form);
+    // variant 1 keeps the register-pass family's MODE 1 / 2 (n_real <= 16384)
+    const bool big64_real = !f32 && p->real_mode && p->twt_big && fft_big64_real_supports(p->n, p->radix);
+    if (big64_real && variant == 0)
+        return { K_BIG64_REAL, "sdsp_fft_big_f64_real_kernel", 1, 2, false, pc && p->n <= 4096 };
+    if (p->path == PATH_REG && !f32 && fft_reg64_supports(p->n, p->radix)) {
+        if ((big64 && big64_variant(p->n) == 0) || big64_real) // the kernel that was the default becomes variant 1
             variant = variant == 1 ? 0 : variant;
         const bool wave64 = !p->real_mode && fft_wave_supports(p->n, p->radix);
         if (variant == 1 && wave64) // N = 1024 alternate: same bits; measured 71.4-72.1 % against 71.7-72.6 %: no gain in double
@@ -523,7 +529,8 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         }
         return launch_fft_big_f32(a, stream);
     }
-    case K_BIG64: {
+    case K_BIG64:
+    case K_BIG64_REAL: {
         fft_reg_args a;
         a.data = data;
         a.tw = p->twt_big;
@@ -533,6 +540,10 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
         a.scale = 1.0f;
         a.scale_d = 1.0 / p->n;
         a.reverse = rev;
+        if (sel.id == K_BIG64_REAL) {
+            a.real_mode = p->real_mode;
+            a.tw2 = p->tw2;
+        }
         a.nontemporal = 1;
         return launch_fft_big_f64(a, stream);
     }
@@ -1082,18 +1093,20 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **out, uint32_t n_real, int ra
         return fail(SDSP_HIP_ERR_INVALID_SIZE, "FFT radix 4 size must be a power of 4! (n_real / 2)");
     if (radix != 2 && radix != 4)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "radix must be 2 or 4");
-    const bool big_real = precision == SDSP_HIP_F32 && fft_big_real_supports(n, radix); // fft_big.hip, REAL
+    const bool big_real = (precision == SDSP_HIP_F32 && fft_big_real_supports(n, radix)) ||   // fft_big.hip, REAL
+                          (precision == SDSP_HIP_F64 && fft_big64_real_supports(n, radix));    // fft_big64.hip, REAL
     if (!big_real && (precision == SDSP_HIP_F32 ? !fft_reg_supports(n, radix) : !fft_reg64_supports(n, radix)))
-        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768 (f32; radix 2: .. 65536) / 32 .. 16384 (f64)");
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans cover n_real = 32 .. 32768 (f32; radix 2: .. 65536) / 32 .. 16384 (f64; radix 2: .. 32768)");
     sdsp_hip_fft_plan *p = nullptr;
     if (int rc = sdsp_hip_fft_plan_create(&p, n, radix, direction, precision, max_batch, device))
         return rc;
     p->path = PATH_REG; // also at n = 4096 f32 (the tuned complex kernels have no split stage)
     p->real_mode = direction == SDSP_HIP_FORWARD ? 1 : 2;
     std::vector<double> w;
-    if (big_real && !p->twt_big) { // (every complex plan this kernel serves has the table already)
+    if (big_real && !p->twt_big) { // (every complex plan these kernels serve has the table already)
         make_twiddles(n, direction, w);
-        if (int rc = big_r4_form(n, radix) ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F32, &p->twt_big) : upload_thread_twiddles_big(w, n, SDSP_HIP_F32, &p->twt_big)) {
+        if (int rc = (precision == SDSP_HIP_F32 && big_r4_form(n, radix)) ? upload_thread_twiddles_big_r4(w, n, SDSP_HIP_F32, &p->twt_big)
+                                                                          : upload_thread_twiddles_big(w, n, precision, &p->twt_big)) {
             sdsp_hip_fft_plan_destroy(p);
             return rc;
         }

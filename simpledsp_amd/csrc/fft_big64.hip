@@ -260,6 +260,107 @@ __global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_conv_kernel
     }
 }
 
+// Real-input packing in double around the same transform: n_real real samples = N = n_real / 2 complex ones.
+// REAL = 1 (forward): transform, then split  X[a] = E + T, X[N-a] = conj(E - T),  E = (Z[a] + conj Z[N-a]) / 2, T = -i W_2N^a (Z[a] - conj Z[N-a]) / 2;
+// REAL = 2 (inverse): merge (the inverse of that), then the reverse transform.  Register r holds element k = t + T b(r), b(r) = r before the
+// transform and bit_reverse5(r) after it; the partner of (t, b) is (T - t, 31 - b).  The lower half of the elements (b < 16) is parked in LDS
+// as complex values -- N/2 x 16 B: the plane's size, + one slot of padding for k = N/2 -- the upper half computes both results of its pair,
+// keeps one and writes the other back (fft_big.hip's scheme).  w2n: W_2N^j, j < 2N, of the plan's direction.
+template <int L, bool MERGE, bool AFTER>
+__device__ __forceinline__ void big64_real_pairs(double2 (&y)[32], const double2 *__restrict__ w2n, uint32_t t)
+{
+    constexpr uint32_t N = 1u << L, T = N / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft_big64_smem[];
+    auto lds_c = [&](uint32_t byte) -> double2 & { return *reinterpret_cast<double2 *>(sdsp_fft_big64_smem + byte); };
+    const __amdgpu_buffer_rsrc_t wrows = make_rows64(w2n, 2 * N * sizeof(double2));
+    if constexpr (AFTER)
+        __syncthreads(); // every wave has read the transform's last plane
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+        if (b < 16)
+            lds_c(16u * t + 16u * T * b) = y[r];
+    }
+    __syncthreads();
+    const bool t0 = t == 0;
+    const uint32_t pbase = 16u * (T - t); // partner of (t, b): slot (T - t) + T (31 - b) = N - k
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+        if (b < 16)
+            continue;
+        const double2 pa = lds_c(pbase + 16u * T * (31 - b));                  // element a = N - k
+        const double2 w = row_load64<false>(wrows, pbase, 16u * T * (31 - b));  // W_2N^a
+        const double2 own = y[r];
+        const double2 e = double2{ 0.5 * (pa.x + own.x), 0.5 * (pa.y - own.y) }; // (A + conj B) / 2
+        const double2 d = double2{ 0.5 * (pa.x - own.x), 0.5 * (pa.y + own.y) }; // (A - conj B) / 2
+        const double2 wd = cmul(d, w);
+        double2 ra, rb;
+        if constexpr (MERGE) { // Z[a] = E + i O, Z[N-a] = conj(E - i O)
+            ra = double2{ e.x - wd.y, e.y + wd.x };
+            rb = double2{ e.x + wd.y, wd.x - e.y };
+        } else { // X[a] = E + T, X[N-a] = conj(E - T), T = -i W D
+            ra = double2{ e.x + wd.y, e.y - wd.x };
+            rb = double2{ e.x - wd.y, -wd.x - e.y };
+        }
+        if (b == 16) { // k = N/2 in thread 0: conj, no partner (the slot it touched is the padding behind the plane)
+            rb.x = t0 ? own.x : rb.x;
+            rb.y = t0 ? -own.y : rb.y;
+        }
+        y[r] = rb;
+        lds_c(pbase + 16u * T * (31 - b)) = ra;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int b = AFTER ? (int)(__brev((uint32_t)r) >> 27) : r;
+        if (b >= 16)
+            continue;
+        double2 v = lds_c(16u * t + 16u * T * b);
+        if (b == 0) { // k = 0 in thread 0: (X[0], X[N]) packed, both real
+            const double2 z = v;
+            const double2 p0 = MERGE ? double2{ 0.5 * (z.x + z.y), 0.5 * (z.x - z.y) } : double2{ z.x + z.y, z.x - z.y };
+            v.x = t0 ? p0.x : v.x;
+            v.y = t0 ? p0.y : v.y;
+        }
+        y[r] = v;
+    }
+}
+
+template <int L, int REAL, bool NT>
+__global__ __launch_bounds__((1 << L) / 32, 2) void sdsp_fft_big_f64_real_kernel(double2 *__restrict__ data, const double2 *__restrict__ tw,
+                                                                                const double2 *__restrict__ w2n, double scale, uint64_t batch)
+{
+    static_assert(REAL == 1 || REAL == 2, "1 = forward (split after the transform), 2 = inverse (merge before it)");
+    constexpr uint32_t N = 1u << L, T = N / 32;
+    const uint32_t t = threadIdx.x;
+    const uint32_t toff = t * 16u;
+    const uint64_t xform = blockIdx.x;
+    if (xform >= batch)
+        return;
+    const __amdgpu_buffer_rsrc_t rows = make_rows64(data + xform * N, N * sizeof(double2));
+    double2 x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        x[k] = row_load64<NT>(rows, toff, T * k * sizeof(double2));
+    if constexpr (REAL == 2) {
+        big64_real_pairs<L, true, false>(x, w2n, t);
+        __syncthreads(); // every wave has read its parked values back: the plane is free for the transform
+    }
+    big64_transform<L, REAL == 2, false, false>(x, tw, t);
+    if constexpr (REAL == 1)
+        big64_real_pairs<L, false, true>(x, w2n, t);
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        double2 o = x[i];
+        if constexpr (REAL == 2) { // reverse_fft::ScaleValues, fft.h:128-132
+            o.x *= scale;
+            o.y *= scale;
+        }
+        row_store64<NT>(rows, toff, T * (__brev((uint32_t)i) >> 27) * sizeof(double2), o);
+    }
+}
+
 template <int L, bool REV, bool R4 = false> int launch_l(const fft_reg_args &a, hipStream_t s)
 {
     constexpr size_t lds = sizeof(double) << L;
@@ -297,8 +398,29 @@ template <int L> int launch_conv_l(const fft_reg_args &a, hipStream_t s)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_big64 convolution launch: ") + hipGetErrorString(e));
     return SDSP_HIP_OK;
 }
+
+template <int L, int REAL> int launch_real_l(const fft_reg_args &a, hipStream_t s)
+{
+    constexpr size_t lds = (sizeof(double) << L) + 16; // one complex slot of padding behind the plane (k = N/2)
+    auto kern = sdsp_fft_big_f64_real_kernel<L, REAL, true>;
+    if constexpr (lds > 64 * 1024) {
+        static std::atomic<uint64_t> attr_done{ 0 };
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done))
+            return rc;
+    }
+    if (a.batch > 0x7fffffffull)
+        return fail(SDSP_HIP_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((uint32_t)a.batch), dim3((1u << L) / 32), lds, s, reinterpret_cast<double2 *>(a.data),
+                       reinterpret_cast<const double2 *>(a.tw), reinterpret_cast<const double2 *>(a.tw2), a.scale_d, a.batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(SDSP_HIP_ERR_HIP, std::string("fft_big64 real-input launch: ") + hipGetErrorString(e));
+    return SDSP_HIP_OK;
+}
 } // namespace
 
+// real-input plans in double, n = n_real / 2 = 4096 / 8192 / 16384, radix-2 stages
+bool fft_big64_real_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384); }
 // the fused convolution in double runs radix-2 stages (a radix-2 plan's table): N = 4096 / 8192 / 16384
 bool fft_big64_conv_supports(uint32_t n, int radix) { return radix == 2 && (n == 4096 || n == 8192 || n == 16384); }
 
@@ -314,6 +436,15 @@ int launch_fft_big_f64(const fft_reg_args &a, void *stream)
     if (a.batch == 0)
         return SDSP_HIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a.real_mode == 1 || a.real_mode == 2) { // real-input plans: W_2N in tw2; the direction is the mode's
+        const bool inv = a.real_mode == 2;
+        switch (a.radix == 2 ? a.n : 0u) {
+        case 4096: return inv ? launch_real_l<12, 2>(a, s) : launch_real_l<12, 1>(a, s);
+        case 8192: return inv ? launch_real_l<13, 2>(a, s) : launch_real_l<13, 1>(a, s);
+        case 16384: return inv ? launch_real_l<14, 2>(a, s) : launch_real_l<14, 1>(a, s);
+        default: return fail(SDSP_HIP_ERR_UNSUPPORTED, "real-input plans in double on this kernel: radix 2, n_real = 8192 / 16384 / 32768");
+        }
+    }
     if (a.real_mode == 3) { // fused convolution: h travels in tw2
         switch (a.radix == 2 ? a.n : 0u) {
         case 4096: return launch_conv_l<12>(a, s);

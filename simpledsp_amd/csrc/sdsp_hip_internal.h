@@ -106,6 +106,7 @@ bool fft_big_conv_supports(uint32_t n, int radix); // fused convolution
 int launch_fft_big_f32(const fft_reg_args &a, void *stream);
 // the same design in double: N = 4096 / 8192 / 16384, radix-2 stages (fft_big64.hip); a.tw = the [pass][stage][thread] table in double
 bool fft_big64_supports(uint32_t n, int radix);
+bool fft_big64_real_supports(uint32_t n, int radix); // the real-input form (real_mode = 1 / 2, W_2N in tw2)
 bool fft_big64_conv_supports(uint32_t n, int radix); // the fused convolution form (launch_fft_big_f64 with real_mode = 3, h in tw2)
 int launch_fft_big_f64(const fft_reg_args &a, void *stream);
 
