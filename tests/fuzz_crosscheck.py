@@ -31,7 +31,10 @@ for case in range(cases):
             log2n = int(rng.integers(1, 23)) if kind == "fft" else int(rng.integers(4, 16))  # up to 2^22 (two-pass since round 3)
             n = 1 << log2n
             radix = 4 if (log2n % 2 == 0 and rng.random() < 0.5) else 2
-            f64 = kind == "fft" and rng.random() < 0.3 and n <= (1 << 20)  # 2^16 .. 2^20: the two-pass kernels in double
+            f64 = rng.random() < 0.3 and n <= ((1 << 20) if kind == "fft" else 16384)  # fft: .. 2^20 (two-pass kernels in double); conv / rfft in
+            # double: .. 16384 (round 3: inside the f64 registers-resident kernel from 4096)
+            if f64 and kind == "rfft" and radix == 4 and n > 4096:
+                radix = 2  # radix-4 real-input plans in double stop at n_real = 8192
             batch = int(rng.integers(1, max(3, min(300, (1 << 18) // n))))
             rev = bool(rng.integers(0, 2))
             cdt = np.complex128 if f64 else np.complex64
@@ -49,30 +52,33 @@ for case in range(cases):
                 err = rel(d.cpu().numpy(), ref)
                 desc = f"fft n={n} r{radix} {'f64' if f64 else 'f32'} batch={batch} rev={rev} var={plan._variant if hasattr(plan, '_variant') else '?'}"
             elif kind == "conv":
-                h = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
-                plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F32, max_batch=batch)
+                h = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+                plan = sd.FftPlan(n, radix, sd.forward_fft, sd.F64 if f64 else sd.F32, max_batch=batch)
                 cvar = int(rng.choice([0, 0, 1, 2]))  # fused kernel of the size / three launches / the register-pass fusion
                 plan.set_variant(cvar)
                 d = torch.from_numpy(x).cuda()
                 plan.convolve(d, torch.from_numpy(h).cuda())
                 torch.cuda.synchronize()
                 ref = np.fft.ifft(np.fft.fft(x.astype(np.complex128), axis=-1) * h.astype(np.complex128), axis=-1)
-                err, tol = rel(d.cpu().numpy(), ref), 2e-6
-                desc = f"conv n={n} r{radix} batch={batch} var={cvar}"
+                err, tol = rel(d.cpu().numpy(), ref), (16 * n * 2.3e-16 if f64 else 2e-6)
+                desc = f"conv n={n} r{radix} {'f64' if f64 else 'f32'} batch={batch} var={cvar}"
             else:
                 n_real = 2 * n
-                xr = rng.standard_normal((batch, n_real)).astype(np.float32)
-                fwd = sd.RfftPlan(n_real, radix, sd.forward_fft, max_batch=batch)
-                inv = sd.RfftPlan(n_real, radix, sd.reverse_fft, max_batch=batch)
+                xr = rng.standard_normal((batch, n_real)).astype(np.float64 if f64 else np.float32)
+                prec = sd.F64 if f64 else sd.F32
+                fwd = sd.RfftPlan(n_real, radix, sd.forward_fft, max_batch=batch, precision=prec)
+                inv = sd.RfftPlan(n_real, radix, sd.reverse_fft, max_batch=batch, precision=prec)
                 rvar = int(rng.choice([0, 0, 1, 2]))  # the size's default kernel / the register-pass family's two cache policies
-                if n > 16384:
-                    rvar = 0  # n_real = 65536 exists in the registers-resident kernel only
+                if n > (8192 if f64 else 16384):
+                    rvar = 0  # n_real = 65536 (double: 32768) exists in the registers-resident kernel only
+                if f64:  # double: one alternate (the register-pass family's MODE 1 / 2), where the registers-resident kernel is the default
+                    rvar = min(rvar, 1) if (radix == 2 and n in (4096, 8192)) else 0
                 fwd.set_variant(rvar)
                 inv.set_variant(int(rng.choice([0, rvar])))
                 d = torch.from_numpy(xr).cuda()
                 fwd.exec(d)
                 torch.cuda.synchronize()
-                spec = d.cpu().numpy().view(np.complex64).reshape(batch, n)
+                spec = d.cpu().numpy().view(cdt).reshape(batch, n)
                 ref = np.fft.rfft(xr.astype(np.float64), axis=-1)
                 got = spec.astype(np.complex128).copy()
                 e0 = np.abs(got[:, 1:] - ref[:, 1:n]).max() / np.abs(ref).max()
@@ -80,8 +86,8 @@ for case in range(cases):
                 inv.exec(d)
                 torch.cuda.synchronize()
                 e2 = rel(d.cpu().numpy(), xr.astype(np.float64))
-                err, tol = max(e0, e1, e2 / 4), 1e-6
-                desc = f"rfft n_real={n_real} r{radix} batch={batch} var={rvar}"
+                err, tol = max(e0, e1, e2 / 4), (8 * n_real * 2.3e-16 if f64 else 1e-6)
+                desc = f"rfft n_real={n_real} r{radix} {'f64' if f64 else 'f32'} batch={batch} var={rvar}"
         elif kind == "iir":
             m = int(rng.choice([2, 4, 6, 8]))
             mode = int(rng.integers(0, 3))  # 0 f32, 1 f64, 2 float samples + double recurrence (SDSP_HIP_F32_F64STATE)
