@@ -146,7 +146,8 @@ int sdsp_hip_fft_exec_sharded(sdsp_hip_fft_plan *const *plans, int n_plans, void
  * policy with its 1/N scale exists for exactly this, fft.h:121-133).  `plan` must be a FORWARD plan;
  * h: DEVICE pointer to n complex values of the plan precision (frequency response, natural order).
  * f32 with n = 16 .. 16384 (radix-2 plans: .. 32768) and f64 with n = 16 .. 8192 (radix-2 plans: .. 16384) run as ONE kernel (one HBM read + one
- * write per element instead of three of each); larger n runs forward, multiply, reverse as three launches.
+ * write per element instead of three of each); larger n runs forward and reverse as two transforms with the multiply riding on the
+ * forward transform's last pass (two-pass sizes) or as a third launch.
  */
 int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *plan, void *data, const void *h, uint64_t batch,
                           void *stream);

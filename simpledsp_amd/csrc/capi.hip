@@ -476,7 +476,8 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
 }
 
 // `variant`: the kernel variant to run (normally the plan's; the convolution path overrides it without touching the plan)
-int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream, int variant)
+// hmul (the two-pass kernels, forward plans): every output leaves multiplied by hmul[k] -- the fused convolution's forward half
+int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_t stream, int variant, const void *hmul = nullptr)
 {
     if (batch == 0 || p->path == PATH_NOOP)
         return SDSP_HIP_OK;
@@ -675,6 +676,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.scale = (float)(1.0 / p->n);
             a.scale_d = 1.0 / p->n;
             a.reverse = rev;
+            a.hmul = hmul;
             if (int rc = launch_fft_2pass_fused(p->precision, a, stream))
                 return rc;
         }
@@ -693,6 +695,7 @@ int fft_exec_device(sdsp_hip_fft_plan *p, void *data, uint64_t batch, hipStream_
             a.scale = (float)(1.0 / p->n);
             a.scale_d = 1.0 / p->n;
             a.reverse = rev;
+            a.hmul = hmul;
             if (int rc = launch_fft_2pass(p->precision, a, stream))
                 return rc;
         }
@@ -1347,9 +1350,15 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
             return rc;
     }
     // PATH_FFT4096 with variant != 0 selects this three-launch path for cross-checking: its transforms run variant 0
-    const int v = p->path == PATH_FFT4096 ? 0 : p->variant;
-    int rc = fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream), v);
-    if (!rc)
+    int v = p->path == PATH_FFT4096 ? 0 : p->variant;
+    // the two-pass sizes: the forward transform's pass 2 multiplies by h on its way out (fft_2pass.hip, HM) -- four passes over HBM
+    // instead of five.  N = 2^20 f32 takes the generic persistent kernel (its variant 2) for that half
+    if (p->path == PATH_FFT1M && v == 0 && select_kernel(p, 2).id == K_2PASS_FUSED)
+        v = 2;
+    const fft_kernel_id fwd_id = select_kernel(p, v).id;
+    const bool fused_mul = fwd_id == K_2PASS || fwd_id == K_2PASS_FUSED;
+    int rc = fft_exec_device(p, data, batch, reinterpret_cast<hipStream_t>(stream), v, fused_mul ? h : nullptr);
+    if (!rc && !fused_mul)
         rc = launch_pointwise_mul(p->precision, data, h, p->n, batch, stream);
     if (!rc)
         rc = fft_exec_device(p->partner, data, batch, reinterpret_cast<hipStream_t>(stream), p->partner->variant);

@@ -158,9 +158,11 @@ __global__ __launch_bounds__(kTile * (1 << (L1 - 5))) void sdsp_fft2p_cols(const
 
 // ---- pass 2: 16 rows of one transform, written transposed; 16 * T2 threads -------------------------------------
 // LDS: plane 16 x N2 floats; wrow = pass 2's thread twiddles [stage][lane] (5 x 32 float2, staged by the caller)
-template <int L, int L1, bool REV, typename C>
+// HM: the fused convolution's forward transform -- every output X[k] leaves multiplied by h_x[k] (same index arithmetic as the store), which
+// saves the composition's separate multiply pass over HBM
+template <int L, int L1, bool REV, typename C, bool HM = false>
 __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t tile, typename w32<C>::real *plane, const C *wrow,
-                                            typename w32<C>::real scale, uint32_t t)
+                                            typename w32<C>::real scale, uint32_t t, const C *h_x = nullptr)
 {
     using Real = typename w32<C>::real;
     constexpr uint32_t ES = (uint32_t)sizeof(C);
@@ -258,6 +260,8 @@ __device__ __forceinline__ void rows_tile2p(const C *ws_x, C *out_x, uint32_t ti
             v.x *= scale;
             v.y *= scale;
         }
+        if constexpr (HM)
+            v = cmul(v, *at(h_x + tile * kTile + (size_t)(__brev((uint32_t)k) >> 27) * ((size_t)N1 << (L2 - 5)), boff));
         nt_store(at(dst_tile + (size_t)(__brev((uint32_t)k) >> 27) * ((size_t)N1 << (L2 - 5)), boff), v);
     }
 }
@@ -269,9 +273,10 @@ template <int L2, typename C> __device__ __forceinline__ void stage_wrow2p(C *wr
     for (uint32_t i = threadIdx.x; i < 5 * 32; i += threads)
         wrow[i] = (i & 31u) < (uint32_t)T2 ? tw_1024[((i & 31u) * (1024 / N2)) << (i >> 5)] : C{ Real(1), Real(0) };
 }
-template <int L, int L1, bool REV, typename C>
+template <int L, int L1, bool REV, typename C, bool HM = false>
 __global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(const C *__restrict__ ws, C *__restrict__ out,
-                                                                              const C *__restrict__ tw_1024, typename w32<C>::real scale)
+                                                                              const C *__restrict__ tw_1024, typename w32<C>::real scale,
+                                                                              const C *__restrict__ hmul)
 {
     using Real = typename w32<C>::real;
     constexpr int L2 = L - L1, N1 = 1 << L1, N2 = 1 << L2, T2 = N2 / 32, THREADS = kTile * T2, TILES = N1 / kTile;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(kTile * (1 << (L - L1 - 5))) void sdsp_fft2p_rows(c
     C *wrow = reinterpret_cast<C *>(sdsp_fft2p_smem + (size_t)N2 * kTile * sizeof(Real));
     stage_wrow2p<L2>(wrow, tw_1024, THREADS);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    rows_tile2p<L, L1, REV, C>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale, threadIdx.x);
+    rows_tile2p<L, L1, REV, C, HM>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale, threadIdx.x, hmul);
 }
 
 template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_args &a, hipStream_t s)
@@ -294,6 +299,12 @@ template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_a
         return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows<L, L1, REV, C>), lds_rows, done_r))
         return rc;
+    if constexpr (!REV) {
+        static std::atomic<uint64_t> done_h{ 0 };
+        if (a.hmul)
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows<L, L1, false, C, true>), lds_rows, done_h))
+                return rc;
+    }
     const uint64_t blocks_c = a.count * (N2 / kTile), blocks_r = a.count * (N1 / kTile);
     if (blocks_c > 0x7fffffffull || blocks_r > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
@@ -301,7 +312,15 @@ template <int L, int L1, bool REV, typename C> int launch_pair(const fft_2pass_a
     const C *tw = reinterpret_cast<const C *>(a.tw_1024);
     const Real scale = sizeof(Real) == 8 ? (Real)a.scale_d : (Real)a.scale;
     hipLaunchKernelGGL((sdsp_fft2p_cols<L, L1, REV, C>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
-    hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV, C>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, scale);
+    const C *hm = reinterpret_cast<const C *>(a.hmul);
+    if constexpr (!REV) {
+        if (hm)
+            hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, false, C, true>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, scale, hm);
+        else
+            hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV, C>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, scale, hm);
+    } else {
+        hipLaunchKernelGGL((sdsp_fft2p_rows<L, L1, REV, C>), dim3((uint32_t)blocks_r), dim3(kTile * (N2 / 32)), lds_rows, s, ws, d, tw, scale, hm);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
@@ -445,8 +464,9 @@ __global__ __launch_bounds__(512) void sdsp_fft2p_cols64(const float2 *__restric
 
 // ---- pass 2 with N2 = 2048: 16 rows, written transposed; 512 threads.  LDS: plane 16 x 2048 floats
 // (slot(row, pos) = row * 2048 + (pos ^ (row | (((pos >> 6) & 1) << 4)))), wrow = [stage < 5][lane] W_1024^(lane << stage), [5][lane] W_2048^lane
-template <int L, int L1, bool REV>
-__device__ __forceinline__ void rows64_tile2p(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *wrow, float scale)
+template <int L, int L1, bool REV, bool HM = false>
+__device__ __forceinline__ void rows64_tile2p(const float2 *ws_x, float2 *out_x, uint32_t tile, float *plane, const float2 *wrow, float scale,
+                                              const float2 *h_x = nullptr)
 {
     constexpr int N1 = 1 << L1, N2 = 2048;
     static_assert(L - L1 == 11, "rows of 2048");
@@ -523,13 +543,17 @@ __device__ __forceinline__ void rows64_tile2p(const float2 *ws_x, float2 *out_x,
             w.y *= scale;
         }
         const size_t k2hi = (size_t)(__brev((uint32_t)j) >> 27) * 64;
+        if constexpr (HM) {
+            v = cmul(v, *at(h_x + tile * kTile + k2hi * N1, boff));
+            w = cmul(w, *at(h_x + tile * kTile + (k2hi + 32) * N1, boff));
+        }
         nt_store(at(dst_tile + k2hi * N1, boff), v);
         nt_store(at(dst_tile + (k2hi + 32) * N1, boff), w);
     }
 }
-template <int L, int L1, bool REV>
+template <int L, int L1, bool REV, bool HM = false>
 __global__ __launch_bounds__(512) void sdsp_fft2p_rows64(const float2 *__restrict__ ws, float2 *__restrict__ out, const float2 *__restrict__ tw_1024,
-                                                        float scale)
+                                                        float scale, const float2 *__restrict__ hmul)
 {
     constexpr int N1 = 1 << L1, N2 = 2048, TILES = N1 / kTile;
     extern __shared__ __attribute__((aligned(16))) unsigned char sdsp_fft2p_smem[];
@@ -538,7 +562,7 @@ __global__ __launch_bounds__(512) void sdsp_fft2p_rows64(const float2 *__restric
     for (uint32_t i = threadIdx.x; i < 6 * 32; i += 512) // [stage][lane] = W_1024^(lane << stage); [5][lane] = W_2048^lane
         wrow[i] = i < 5 * 32 ? tw_1024[(i & 31u) << (i >> 5)] : w2048<REV>(tw_1024, i & 31u);
     const size_t xoff = (size_t)(blockIdx.x / TILES) << L;
-    rows64_tile2p<L, L1, REV>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale);
+    rows64_tile2p<L, L1, REV, HM>(ws + xoff, out + xoff, blockIdx.x % TILES, plane, wrow, scale, hmul);
 }
 
 // N = 2^21: the 32-point column pass above (N1 = 1024) + rows of 2048; N = 2^22: both passes of 2048
@@ -553,6 +577,12 @@ template <int L, bool REV> int launch_pair64(const fft_2pass_args &a, hipStream_
         return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows64<L, L1, REV>), lds_rows, done_r))
         return rc;
+    if constexpr (!REV) {
+        static std::atomic<uint64_t> done_h{ 0 };
+        if (a.hmul)
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sdsp_fft2p_rows64<L, L1, false, true>), lds_rows, done_h))
+                return rc;
+    }
     const uint64_t blocks_c = a.count * (N2 / kTile), blocks_r = a.count * (N1 / kTile);
     if (blocks_c > 0x7fffffffull || blocks_r > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "chunk too large for one launch");
@@ -562,7 +592,15 @@ template <int L, bool REV> int launch_pair64(const fft_2pass_args &a, hipStream_
         hipLaunchKernelGGL((sdsp_fft2p_cols<L, 10, REV, float2>), dim3((uint32_t)blocks_c), dim3(kTile * (N1 / 32)), lds_cols, s, d, ws, tw);
     else
         hipLaunchKernelGGL((sdsp_fft2p_cols64<22, REV>), dim3((uint32_t)blocks_c), dim3(512), lds_cols, s, d, ws, tw);
-    hipLaunchKernelGGL((sdsp_fft2p_rows64<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(512), lds_rows, s, ws, d, tw, a.scale);
+    const float2 *hm = reinterpret_cast<const float2 *>(a.hmul);
+    if constexpr (!REV) {
+        if (hm)
+            hipLaunchKernelGGL((sdsp_fft2p_rows64<L, L1, false, true>), dim3((uint32_t)blocks_r), dim3(512), lds_rows, s, ws, d, tw, a.scale, hm);
+        else
+            hipLaunchKernelGGL((sdsp_fft2p_rows64<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(512), lds_rows, s, ws, d, tw, a.scale, hm);
+    } else {
+        hipLaunchKernelGGL((sdsp_fft2p_rows64<L, L1, REV>), dim3((uint32_t)blocks_r), dim3(512), lds_rows, s, ws, d, tw, a.scale, hm);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass launch: ") + hipGetErrorString(e));
@@ -589,6 +627,7 @@ struct fused2p_kargs {
     float scale;
     double scale_d;
     unsigned long long spin_limit;
+    const void *hmul;    // HM instances: the frequency response the forward transform's outputs are multiplied by (fused convolution)
 };
 
 // the thread index as a value the compiler cannot prove loop-invariant: the per-thread addresses of BOTH tile functions would
@@ -633,13 +672,14 @@ template <int L_, int L1_, typename C_, int MIN_THREADS = 64> struct shape32 {
         cols_tile2p<L, L1, REV, C, true>(in_x, ws_x, item * GC + g, reinterpret_cast<Real *>(smem) + (size_t)g * N1 * kTile,
                                          reinterpret_cast<const C *>(smem + W1K), reinterpret_cast<C *>(smem + QTAB) + g * 32 * kTile, t);
     }
-    template <bool REV> static __device__ __forceinline__ void rows(const C *ws_x, C *out_x, uint32_t item, unsigned char *smem, Real scale)
+    template <bool REV, bool HM>
+    static __device__ __forceinline__ void rows(const C *ws_x, C *out_x, uint32_t item, unsigned char *smem, Real scale, const C *h_x)
     {
         const uint32_t tid = fresh_tid();
         const uint32_t g = tid / THREADS_R, t = tid % THREADS_R;
         stage_wrow2p<L2>(reinterpret_cast<C *>(smem + WROW), reinterpret_cast<const C *>(smem + W1K), THREADS);
-        rows_tile2p<L, L1, REV, C>(ws_x, out_x, item * GR + g, reinterpret_cast<Real *>(smem) + (size_t)g * N2 * kTile,
-                                   reinterpret_cast<const C *>(smem + WROW), scale, t);
+        rows_tile2p<L, L1, REV, C, HM>(ws_x, out_x, item * GR + g, reinterpret_cast<Real *>(smem) + (size_t)g * N2 * kTile,
+                                       reinterpret_cast<const C *>(smem + WROW), scale, t, h_x);
     }
 };
 // N = 2^21 (1024 x 2048) and 2^22 (2048 x 2048), f32: the 64-points-per-thread passes
@@ -668,13 +708,14 @@ template <int L_> struct shape64 {
         else
             cols64_tile2p<L, REV, true>(in_x, ws_x, item, plane, w1k, qtab);
     }
-    template <bool REV> static __device__ __forceinline__ void rows(const float2 *ws_x, float2 *out_x, uint32_t item, unsigned char *smem, float scale)
+    template <bool REV, bool HM>
+    static __device__ __forceinline__ void rows(const float2 *ws_x, float2 *out_x, uint32_t item, unsigned char *smem, float scale, const float2 *h_x)
     {
-        rows64_tile2p<L, L1, REV>(ws_x, out_x, item, reinterpret_cast<float *>(smem), reinterpret_cast<const float2 *>(smem + WROW), scale);
+        rows64_tile2p<L, L1, REV, HM>(ws_x, out_x, item, reinterpret_cast<float *>(smem), reinterpret_cast<const float2 *>(smem + WROW), scale, h_x);
     }
 };
 
-template <class S, bool REV> __global__ __launch_bounds__(S::THREADS, S::MIN_WAVES) void sdsp_fft2p_fused(fused2p_kargs a)
+template <class S, bool REV, bool HM = false> __global__ __launch_bounds__(S::THREADS, S::MIN_WAVES) void sdsp_fft2p_fused(fused2p_kargs a)
 {
     using C = typename S::C;
     using Real = typename S::Real;
@@ -760,7 +801,8 @@ template <class S, bool REV> __global__ __launch_bounds__(S::THREADS, S::MIN_WAV
         if (first)
             S::template cols<REV>(data_x, ws_x, item_x, sdsp_fft2p_smem);
         else
-            S::template rows<REV>(ws_x, data_x, item_x, sdsp_fft2p_smem, sizeof(Real) == 8 ? (Real)a.scale_d : (Real)a.scale);
+            S::template rows<REV, HM>(ws_x, data_x, item_x, sdsp_fft2p_smem, sizeof(Real) == 8 ? (Real)a.scale_d : (Real)a.scale,
+                                      reinterpret_cast<const C *>(a.hmul));
 
         // ---- publish: pass 1 hands its output to other workgroups (write-through stores: drained = at the fabric); pass 2
         // frees the ring slot -- its loads of the slot have returned (their values fed the butterflies)
@@ -777,9 +819,9 @@ template <class S, bool REV> __global__ __launch_bounds__(S::THREADS, S::MIN_WAV
     }
 }
 
-template <class S, bool REV> int launch_fused_s(const fft_2pass_fused_args &a, hipStream_t s)
+template <class S, bool REV, bool HM = false> int launch_fused_s(const fft_2pass_fused_args &a, hipStream_t s)
 {
-    auto kern = sdsp_fft2p_fused<S, REV>;
+    auto kern = sdsp_fft2p_fused<S, REV, HM>;
     static std::atomic<uint64_t> lds_done{ 0 };
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), S::LDS, lds_done))
         return rc;
@@ -815,6 +857,7 @@ template <class S, bool REV> int launch_fused_s(const fft_2pass_fused_args &a, h
     k.scale = a.scale;
     k.scale_d = a.scale_d;
     k.spin_limit = a.spin_limit;
+    k.hmul = a.hmul;
     hipError_t e = hipMemsetAsync(a.sync, 0, fft_2pass_sync_bytes(units, a.queues), s);
     if (e != hipSuccess)
         return fail(SDSP_HIP_ERR_HIP, std::string("fft_2pass fused memset: ") + hipGetErrorString(e));
@@ -826,7 +869,9 @@ template <class S, bool REV> int launch_fused_s(const fft_2pass_fused_args &a, h
 }
 template <class S> int launch_fused_dir(const fft_2pass_fused_args &a, hipStream_t s)
 {
-    return a.reverse ? launch_fused_s<S, true>(a, s) : launch_fused_s<S, false>(a, s);
+    if (a.hmul && a.reverse)
+        return fail(SDSP_HIP_ERR_INVALID_ARG, "fft_2pass: the multiply rides on the forward transform");
+    return a.reverse ? launch_fused_s<S, true>(a, s) : a.hmul ? launch_fused_s<S, false, true>(a, s) : launch_fused_s<S, false>(a, s);
 }
 
 template <int L, int L1, typename C> int launch_dir(const fft_2pass_args &a, hipStream_t s)

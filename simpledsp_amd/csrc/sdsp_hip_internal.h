@@ -133,6 +133,7 @@ struct fft_2pass_args {
     float scale;
     int reverse;
     double scale_d = 1.0; // f64
+    const void *hmul = nullptr; // forward only: every output X[k] leaves multiplied by hmul[k] (the fused convolution's forward half)
 };
 bool fft_2pass_supports(uint32_t n, int precision);
 int launch_fft_2pass(int precision, const fft_2pass_args &a, void *stream);
@@ -186,6 +187,7 @@ struct fft_2pass_fused_args {
     float scale;
     double scale_d;
     int reverse;
+    const void *hmul = nullptr; // forward only: every output X[k] leaves multiplied by hmul[k]
 };
 size_t fft_2pass_sync_bytes(uint64_t units, uint32_t queues);
 void fft_2pass_fused_shape(uint32_t n, int precision, uint32_t *unit, uint32_t *queues, uint32_t *ring, uint32_t *lag);
