@@ -177,7 +177,8 @@ int sdsp_hip_rfft_plan_create_p(sdsp_hip_fft_plan **plan, uint32_t n_real, int r
  * wait that gives up marks the call (a sticky word that every launch of the call can set and only the next call clears)
  * instead of hanging the GPU: this returns SDSP_HIP_ERR_HIP then, SDSP_HIP_OK otherwise (always OK for plans whose kernels
  * have no in-kernel hand-off).  The synchronous sdsp_hip_fft_exec_host checks the same word itself and returns the error;
- * ASYNCHRONOUS callers of such plans (sdsp_hip_fft_exec) must call this before trusting the output.  Has no reference
+ * ASYNCHRONOUS callers of such plans (sdsp_hip_fft_exec, sdsp_hip_fft_convolve -- whose reverse half is covered too) must call this
+ * before trusting the output.  Has no reference
  * counterpart. */
 int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *plan);
 /* Testing hook for the error path above: the bound of the hand-off waits in 100 MHz ticks (default 200 000 000 = 2 s);

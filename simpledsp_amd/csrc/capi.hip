@@ -1258,6 +1258,11 @@ int sdsp_hip_fft_convolve(sdsp_hip_fft_plan *p, void *data, const void *h, uint6
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "convolve needs a complex plan (real-input plans are not supported)");
     if (int rc = use_device(p->device))
         return rc;
+    // this call's launches report into clean sticky abort words (the persistent two-pass kernels; forward and reverse half)
+    if (p->sync)
+        HIP_TRY(hipMemsetAsync(fft1m_sticky(p), 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)));
+    if (p->partner && p->partner->sync)
+        HIP_TRY(hipMemsetAsync(fft1m_sticky(p->partner), 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)));
     // launch pieces as in sdsp_hip_fft_exec (N <= 8192, single-launch kernels); the three-launch composition runs piece by piece
     const bool single = (p->path == PATH_FFT4096 || p->path == PATH_REG || p->path == PATH_TILE) && p->n <= 8192;
     const uint64_t row_bytes = (uint64_t)p->n * esize(p->precision);
@@ -1348,6 +1353,7 @@ static int convolve_device(sdsp_hip_fft_plan *p, void *data, const void *h, uint
         if (int rc = sdsp_hip_fft_plan_create(&p->partner, p->n, p->radix, SDSP_HIP_REVERSE, p->precision,
                                               p->max_batch, p->device))
             return rc;
+        p->partner->wait_limit = p->wait_limit;
     }
     // PATH_FFT4096 with variant != 0 selects this three-launch path for cross-checking: its transforms run variant 0
     int v = p->path == PATH_FFT4096 ? 0 : p->variant;
@@ -1393,7 +1399,10 @@ int sdsp_hip_fft_plan_status(sdsp_hip_fft_plan *p)
     if (int rc = use_device(p->device))
         return rc;
     HIP_TRY(hipDeviceSynchronize());
-    return fft1m_check_sticky(p);
+    if (int rc = fft1m_check_sticky(p))
+        return rc;
+    // sdsp_hip_fft_convolve runs its reverse half on the plan's partner: a hand-off lost there belongs to this plan's last call too
+    return p->partner ? fft1m_check_sticky(p->partner) : SDSP_HIP_OK;
 }
 
 int sdsp_hip_fft_plan_set_wait_limit(sdsp_hip_fft_plan *p, uint64_t ticks)
@@ -1401,6 +1410,8 @@ int sdsp_hip_fft_plan_set_wait_limit(sdsp_hip_fft_plan *p, uint64_t ticks)
     if (!p)
         return fail(SDSP_HIP_ERR_INVALID_ARG, "plan is null");
     p->wait_limit = ticks;
+    if (p->partner)
+        p->partner->wait_limit = ticks;
     return SDSP_HIP_OK;
 }
 

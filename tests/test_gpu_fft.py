@@ -963,6 +963,23 @@ def test_two_pass_lost_handoff_is_reported(sd, torch_cuda):
     plan.status()
     want = np.fft.fft(x[[0, batch - 1]].astype(np.complex128), axis=-1)
     assert rel_max_err(y[[0, batch - 1]], want) < TOL32
+    # the convolution's two halves run persistent launches too (the reverse one on the plan's partner): a lost hand-off in either is this
+    # plan's to report, and the next healthy call clears it
+    h = torch.from_numpy((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)).cuda()
+    d = torch.from_numpy(x).cuda()
+    plan.convolve(d, h)
+    plan.status()
+    ref = np.fft.ifft(np.fft.fft(x[[0]].astype(np.complex128), axis=-1) * h.cpu().numpy().astype(np.complex128), axis=-1)
+    assert rel_max_err(d[[0]].cpu().numpy(), ref) < 2e-6
+    plan.set_wait_limit(0)
+    plan.convolve(d, h)
+    with pytest.raises(sd.SdspHipError):
+        plan.status()
+    plan.set_wait_limit(200_000_000)
+    d = torch.from_numpy(x).cuda()
+    plan.convolve(d, h)
+    plan.status()
+    assert rel_max_err(d[[0]].cpu().numpy(), ref) < 2e-6
 
 
 def test_bench_under_torch_distributed_run_on_one_gpu(sd, torch_cuda):
