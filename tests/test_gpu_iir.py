@@ -235,6 +235,40 @@ def test_wide_supertile_kernel_is_bit_identical(sd, torch_cuda, precision):
             assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("prec_name", ["f32", "f64"])
+def test_block_streaming_is_stream_capturable(sd, torch_cuda, prec_name):
+    """sdsp_hip_iir_process only launches: a block-by-block streaming loop (the reference's testIIR.cpp:61-75 pattern: state carried in the
+    bank) captured into ONE graph and replayed gives the bits of the eager loop -- the launch-bound shape a caller would capture."""
+    torch = torch_cuda
+    prec = sd.F64 if prec_name == "f64" else sd.F32
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((256, 4096)).astype(np.float64 if prec == sd.F64 else np.float32)
+    outs = []
+    for captured in (False, True):
+        bank = _bank(sd, 4, 256, prec, sd.IIR_GENERIC, 1, 10e3, 100e3, 1.1)
+        d = torch.from_numpy(x.copy()).cuda()
+        bank.process(d, samples=128, offset=0)  # first block eagerly (also: one-time queries)
+        torch.cuda.synchronize()
+
+        def blocks():
+            for off in range(128, 4096, 128):
+                bank.process(d, samples=128, offset=off)
+        if captured:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(graph, stream=s):
+                    blocks()
+            torch.cuda.current_stream().wait_stream(s)
+            graph.replay()
+        else:
+            blocks()
+        torch.cuda.synchronize()
+        outs.append((d.cpu().numpy(), bank.state.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("m", [2, 4])
 def test_landing_slot_kernel_is_bit_identical(sd, torch_cuda, m):
     """round 3: the default kernel of f32 banks with m_t <= 4 on whole [64 channels x 512 bytes] tiles is the landing-slot
