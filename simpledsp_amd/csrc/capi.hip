@@ -432,13 +432,16 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
             return { K_REG64, "sdsp_fft_reg_f64_kernel", 1, p->radix, false, pc };
     }
     if (p->path == PATH_REG && f32 && variant < 3) {
-        // one-wave kernels (fft_wave.hip), where they measured faster than the register-pass family.  Complex transform:
-        // N = 1024 (either stage type), N = 256 / 2048 radix 2 (N = 512: 72.1-72.8 % against 74.2-74.8 % there).  Real-input
-        // plans (split / merge by ds_bpermute): n_real = 512 / 1024 / 2048 radix 2: 71.9 / 70.5 / 67.3 % against 70.6 / 66.5 /
-        // 66.2 % (radix 4 at 2048: 65.5 / 65.6: stays with the family; n_real = 4096 .. 65536 radix 2 were taken by K_BIG_REAL above)
-        if (variant == 0 && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
+        // Complex plans: the register-pass family (fft_reg.hip) at every N <= 2048 since its tiles are 2048 points (eight 128-thread
+        // workgroups per CU instead of four of 256; round 3): 75.8-78.9 % of HBM peak at N = 16 .. 2048, either radix, in one call,
+        // where it measured 68-74 % with 4096-point tiles and the one-wave kernels (fft_wave.hip) 72.5 / 74.7 / 74.2 % at N = 256 /
+        // 1024 / 2048 -- those are variant 2 of their sizes now (variant 1: the family with the default cache policy).
+        // Real-input plans keep the one-wave kernels (split / merge by ds_bpermute) as their default: n_real = 512 / 1024 / 2048 radix 2
+        // (radix 4 at 2048 stays with the family; n_real = 4096 .. 65536 radix 2 were taken by K_BIG_REAL above)
+        const int wave_variant = p->real_mode ? 0 : 2;
+        if (variant == wave_variant && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
             return { K_WAVE1024, "sdsp_fft1024_wave", 1, p->radix, false, pc };
-        if (variant == 0 && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
+        if (variant == wave_variant && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))
             return { K_WAVE2, "sdsp_fft_wave_f32", 1, p->radix, false, pc };
         return { K_REG32, "sdsp_fft_reg_kernel", 1, p->radix, false, pc };
     }

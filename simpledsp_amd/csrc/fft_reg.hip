@@ -2,8 +2,8 @@
 // (sdsp::fft_radix2, fft.h:258-299) or radix-4 stages (sdsp::fft_radix4, fft.h:301-360), forward
 // or reverse.  Fast path for every batched size the tuned N=4096 radix-4 kernel does not cover.
 //
-// A 256-thread workgroup owns 4096 complex points = 4096/N consecutive transforms (32 KiB of the
-// batch, contiguous in HBM); for N = 8192 / 16384 a 512- / 1024-thread workgroup owns one transform:
+// A 128-thread workgroup owns 2048 complex points = 2048/N consecutive transforms (16 KiB of the
+// batch, contiguous in HBM; N = 4096: 256 threads, one transform); for N = 8192 / 16384 a 512- / 1024-thread workgroup owns one transform:
 //   1. the 32 KiB are copied HBM -> LDS with 16-byte lanes (fully coalesced, any N);
 //   2. ceil(log2 N / 4) passes: a thread pulls 16 points (stride N/16^(i+1)) of one transform from
 //      LDS into registers, runs four radix-2 DIF stages -- or two radix-4 DIF stages -- on them and
@@ -52,9 +52,12 @@ template <bool NT> __device__ __forceinline__ void gstore16(float4 *p, float4 a)
     }
 }
 
-// complex points per workgroup: 4096 (256 threads), or one whole transform for N = 8192 / 16384
-// (512 / 1024 threads); LDS holds them with one padding slot per 16
-constexpr int points_for(int log2n) { return log2n > 12 ? (1 << log2n) : 4096; }
+// complex points per workgroup: 2048 (128 threads) up to N = 2048, one whole transform above (256 / 512 / 1024 threads); LDS holds them
+// with one padding slot per 16.  Round 3: the tile was 4096 points for every N <= 4096 -- four 256-thread workgroups per CU, whose load /
+// compute / store phases are too coarse to keep the memory pipeline full: 68-74 % of HBM peak at N = 16 .. 2048.  With 2048-point tiles
+// (eight workgroups of 128 per CU, the same bytes in LDS) the same kernel measures 75.8-78.9 % at every one of those sizes, either radix,
+// one call (1024-point tiles: 77.1 % at N = 16, 74.5 % at 64 / 128, 76.4 % at 512: 2048 is the better compromise)
+constexpr int points_for(int log2n) { return log2n > 12 ? (1 << log2n) : (log2n <= 11 ? 2048 : 4096); }
 __device__ __forceinline__ uint32_t slot(uint32_t p) { return p + (p >> 4); }
 
 // reversed index of q within an N-point transform: bit reversal (radix 2) or base-4 digit reversal

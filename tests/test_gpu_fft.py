@@ -121,7 +121,8 @@ def test_every_size_against_oracle(sd, torch_cuda, oracle, radix, precision):
                                            (512, 2, 9), (512, 2, 1031), (256, 2, 4098), (256, 2, 3), (256, 4, 4099), (256, 4, 2), (2048, 2, 130), (1024, 2, 7), (1024, 4, 5), (1024, 4, 1001), (1024, 2, 64), (2048, 2, 3), (4096, 2, 5),
                                            (8192, 2, 3), (16384, 2, 2), (16384, 4, 3)])
 def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, radix, batch):
-    # f32 sizes 16..4096 run through csrc/fft_reg.hip (4096/n transforms per workgroup: ragged tails)
+    # f32 sizes 16..2048 run through csrc/fft_reg.hip (2048/n transforms per workgroup: ragged tails); the one-wave kernels of
+    # csrc/fft_wave.hip (N = 256 / 1024 / 2048) are their sizes' variant 2 since the family's tiles shrank to 2048 points (round 3)
     torch = torch_cuda
     rng = np.random.default_rng(n * 7 + batch)
     x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
@@ -133,14 +134,14 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
         mix = (n, radix) == (16384, 4)
         wave2 = (radix == 2 and n in (256, 2048)) or (radix == 4 and n == 256)  # csrc/fft_wave.hip: 1024 points (or one transform of 2048) per wave
         assert plan.info.kernel.decode() == ("sdsp_fft4096_r2_f32" if (n, radix) == (4096, 2) else
-                                             "sdsp_fft_big_kernel" if big else
-                                             "sdsp_fft1024_wave" if n == 1024 else  # csrc/fft_wave.hip: one transform per wave
-                                             "sdsp_fft_wave_f32" if wave2 else "sdsp_fft_reg_kernel")
+                                             "sdsp_fft_big_kernel" if big else "sdsp_fft_reg_kernel")
         outs = []
-        # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel (, the size's tuned kernel)
-        # N = 1024: variant 0 is the one-wave kernel, which runs the register-pass family's arithmetic: the same bits
-        for variant in ((2, 1, 99, 0) if (n, radix) == (4096, 2) or big else (0, 1, 99, 2) if n == 1024 else (0, 1, 99)):
+        # register-pass family streaming / default policy (mix sizes: fft_big), coverage kernel, and the size's other kernel: the tuned one
+        # (4096 radix 2, N >= 8192) or the one-wave kernel (N = 256 / 1024 / 2048: variant 2; N = 1024's runs the family's arithmetic: same bits)
+        for variant in ((2, 1, 99, 0) if (n, radix) == (4096, 2) or big else (0, 1, 99, 2)):
             plan.set_variant(variant)
+            if variant == 2 and not big and (n, radix) != (4096, 2):
+                assert plan.info.kernel.decode() == ("sdsp_fft1024_wave" if n == 1024 else "sdsp_fft_wave_f32" if wave2 else "sdsp_fft_reg_kernel")
             d = torch.from_numpy(x).cuda()
             guard = torch.full((64,), 7.0 + 3.0j, dtype=torch.complex64, device="cuda")  # overrun detector
             plan.exec(d)
@@ -148,10 +149,12 @@ def test_register_pass_family_ragged_and_variants(sd, torch_cuda, oracle, n, rad
             outs.append(d.cpu().numpy())
             assert rel_max_err(outs[-1], want) < TOL32, (n, radix, rev, variant, rel_max_err(outs[-1], want))
             assert bool((guard == 7.0 + 3.0j).all())
+        if not mix:
+            assert np.array_equal(outs[0], outs[1])  # the same kernel with the other cache policy
         if wave2:  # passes of log2(N / 64) stages instead of four: another split of the same twiddles, not the same roundings
-            assert rel_max_err(outs[0], outs[1]) < 1e-6
-        elif not mix:
-            assert np.array_equal(outs[0], outs[1])
+            assert rel_max_err(outs[0], outs[3]) < 1e-6
+        elif n == 1024:
+            assert np.array_equal(outs[0], outs[3])
 
 
 @pytest.mark.parametrize("n,radix,ref_radix", [(8192, 0, 2), (16384, 4, 4)])
@@ -751,10 +754,10 @@ def test_convolve_launch_pieces_are_bit_identical(sd, torch_cuda, n, radix, prec
 STAGES_2_THEN_4 = 24
 SIZE_TABLE = [
     (16, 2, "f32", "sdsp_fft_reg_kernel", 1, 2), (64, 4, "f32", "sdsp_fft_reg_kernel", 1, 4),
-    (256, 2, "f32", "sdsp_fft_wave_f32", 1, 2), (256, 4, "f32", "sdsp_fft_wave_f32", 1, 4),
+    (256, 2, "f32", "sdsp_fft_reg_kernel", 1, 2), (256, 4, "f32", "sdsp_fft_reg_kernel", 1, 4),
     (512, 2, "f32", "sdsp_fft_reg_kernel", 1, 2),
-    (1024, 2, "f32", "sdsp_fft1024_wave", 1, 2), (1024, 4, "f32", "sdsp_fft1024_wave", 1, 4),
-    (2048, 2, "f32", "sdsp_fft_wave_f32", 1, 2),
+    (1024, 2, "f32", "sdsp_fft_reg_kernel", 1, 2), (1024, 4, "f32", "sdsp_fft_reg_kernel", 1, 4),
+    (2048, 2, "f32", "sdsp_fft_reg_kernel", 1, 2),
     (4096, 2, "f32", "sdsp_fft4096_r2_f32", 1, 2), (4096, 4, "f32", "sdsp_fft4096_r4_f32", 1, 4),
     (8192, 2, "f32", "sdsp_fft_big_kernel", 1, 2), (8192, 0, "f32", "sdsp_fft_big_kernel", 1, 2),
     (16384, 2, "f32", "sdsp_fft_big_kernel", 1, 2), (16384, 4, "f32", "sdsp_fft_big_kernel", 1, 4),
