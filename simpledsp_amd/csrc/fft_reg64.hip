@@ -3,8 +3,8 @@
 // reference computes in double; this is the batched fast path for callers who keep that precision
 // (sdsp::fft_plan<double>).  Same structure as fft_reg.hip: coalesced 16-byte copies HBM <-> LDS,
 // ceil(log2 N / 4) in-LDS passes of four radix-2 (two radix-4) DIF stages on 16 registers, bit / digit
-// reversal folded into the final LDS read.  A workgroup owns max(N, 2048) points (34 KiB of LDS at
-// 2048).  Results agree with the reference to its own bound 4*N*eps (tests/test_gpu_fft.py).
+// reversal folded into the final LDS read.  A workgroup owns max(N, 1024) points (17 KiB of LDS at
+// 1024; N = 2048: 34 KiB).  Results agree with the reference to its own bound 4*N*eps (tests/test_gpu_fft.py).
 #include <hip/hip_runtime.h>
 
 #include "fft_passes.h"
@@ -26,7 +26,9 @@ __device__ __forceinline__ void nt_store(double2 *p, double2 a)
     __builtin_nontemporal_store(v, reinterpret_cast<v2d_t *>(p));
 }
 
-constexpr int points64_for(int log2n) { return log2n > 11 ? (1 << log2n) : 2048; }
+// Round 3: 1024-point tiles (one wave, 17 KiB of LDS: nine workgroups per CU) up to N = 1024 -- with 2048-point tiles (four 128-thread
+// workgroups per CU) the family measured 68-71 % of HBM peak at N = 16 .. 1024, with these 75.3-77.2 % (the f32 family's finding, fft_reg.hip)
+constexpr int points64_for(int log2n) { return log2n > 11 ? (1 << log2n) : (log2n <= 10 ? 1024 : 2048); }
 __device__ __forceinline__ uint32_t slot(uint32_t p) { return p + (p >> 4); }
 template <int RADIX, int LOG2N> __device__ __forceinline__ uint32_t reversed(uint32_t q)
 {
