@@ -228,8 +228,8 @@ int sdsp_hip_fft_plan_get_twiddles(const sdsp_hip_fft_plan *plan, void *host_out
  * persistent launch's 256 MiB ring of intermediates run the two launches under either number; n = 2^20 f32: 1 = two launches per chunk, 2 = the persistent launch through
  * fft_2pass.hip's generic kernel instead of the dedicated one (42.3 against 42.7 % of HBM peak); n = 16 .. 2048 f32 (the register-pass family, fft_reg.hip): 1 = the
  * same kernel with the default cache policy, 2 = the one-wave kernel (fft_wave.hip) at n = 256 / 1024 / 2048; real-input plans of
- * n_real = 512 / 1024 / 2048, whose default IS the one-wave kernel: 1, 2 = the register-pass family with the default / streaming cache
- * policy; the same as variant 2 of sdsp_hip_fft_convolve for the fused convolution of n = 256 .. 2048 (default: the one-wave kernel); f64 n = 1024: 1 = the one-wave kernel); any larger number selects the untuned coverage kernel
+ * n_real = 1024, whose default IS the one-wave kernel: 1, 2 = the register-pass family with the default / streaming cache
+ * policy (n_real = 512 / 2048: as the complex plans); the same as variant 2 of sdsp_hip_fft_convolve for the fused convolution of n = 256 .. 2048 (default: the one-wave kernel); f64 n = 1024: 1 = the one-wave kernel); any larger number selects the untuned coverage kernel
  * (fft_tile.hip), which the tests use as an independent implementation. */
 int sdsp_hip_fft_plan_set_variant(sdsp_hip_fft_plan *plan, int variant);
 

@@ -436,9 +436,10 @@ fft_kernel_sel select_kernel(const sdsp_hip_fft_plan *p, int variant)
         // workgroups per CU instead of four of 256; round 3): 75.8-78.9 % of HBM peak at N = 16 .. 2048, either radix, in one call,
         // where it measured 68-74 % with 4096-point tiles and the one-wave kernels (fft_wave.hip) 72.5 / 74.7 / 74.2 % at N = 256 /
         // 1024 / 2048 -- those are variant 2 of their sizes now (variant 1: the family with the default cache policy).
-        // Real-input plans keep the one-wave kernels (split / merge by ds_bpermute) as their default: n_real = 512 / 1024 / 2048 radix 2
-        // (radix 4 at 2048 stays with the family; n_real = 4096 .. 65536 radix 2 were taken by K_BIG_REAL above)
-        const int wave_variant = p->real_mode ? 0 : 2;
+        // Real-input plans (the one-wave kernels split / merge by ds_bpermute, the family in LDS): with the 2048-point tiles the family
+        // leads at n_real = 512 (74.7 against 71.8 %; radix 4: 75.5 / 71.0) and 2048 (70.5 / 67.2), the one-wave kernel keeps n_real = 1024
+        // (70.8 / 69.8) -- tools/rfft_probe.py, one call each; n_real = 4096 .. 65536 radix 2 were taken by K_BIG_REAL above
+        const int wave_variant = (p->real_mode && p->n == 512) ? 0 : 2;
         if (variant == wave_variant && fft_wave_supports(p->n, p->radix) && (!p->real_mode || p->radix == 2))
             return { K_WAVE1024, "sdsp_fft1024_wave", 1, p->radix, false, pc };
         if (variant == wave_variant && p->twt_wave && (p->real_mode ? p->n <= 512 : p->n != 512))

@@ -533,9 +533,10 @@ def test_real_input_packing(sd, torch_cuda, oracle, n_real, radix, batch, precis
     again = inv.exec(torch.view_as_real(spec).reshape(batch, n_real))
     torch.cuda.synchronize()
     assert rel_max_err(again.cpu().numpy(), x) < 2 * TOL
-    # f32, n_real / 2 = 256 .. 2048: variant 0 is a one-wave kernel whose split / merge trades partners by ds_bpermute
-    # (csrc/fft_wave.hip: real_pack_stage); variant 1 the register-pass family's in-LDS split: the same numbers to rounding
-    wave = not f64 and (half == 256 or (radix == 2 and half in (512, 1024)))  # where the wave kernels measured faster (capi.hip)
+    # f32, n_real = 1024: variant 0 is a one-wave kernel whose split / merge trades partners by ds_bpermute (csrc/fft_wave.hip:
+    # real_pack_stage); variant 1 the register-pass family's in-LDS split: the same numbers to rounding.  (n_real = 512 / 2048: the family
+    # is the default since its tiles are 2048 points, the one-wave kernels their variant 2)
+    wave = not f64 and radix == 2 and half == 512  # where the wave kernels measured faster (capi.hip; round 3: only n_real = 1024 is left)
     # f32, radix 2, n_real / 2 = 8192 / 16384: split / merge inside the registers-resident kernel (csrc/fft_big.hip, REAL: the pairs
     # meet in LDS); variant 1 the register-pass family's, as above
     big = not f64 and ((radix == 2 and half in (2048, 4096, 8192, 16384, 32768)) or (radix == 4 and half in (4096, 16384)))

@@ -16,7 +16,7 @@ sd.load()
 x = torch.randn((batch, n_real), device="cuda", dtype=torch.float32)
 fwd = sd.RfftPlan(n_real, radix, sd.forward_fft, max_batch=batch)
 inv = sd.RfftPlan(n_real, radix, sd.reverse_fft, max_batch=batch)
-for variant in (0, 1, 0, 1):
+for variant in (0, 1, 2, 0, 1, 2):
     fwd.set_variant(variant)
     inv.set_variant(variant)
     for _ in range(5):
