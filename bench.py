@@ -506,7 +506,9 @@ def main():
                                      # two passes over HBM in one persistent launch (fft_2pass.hip), and the f64 single-pass sizes
                                      ("fft", 1 << 16, 2, "f32"), ("fft", 1 << 19, 2, "f32"), ("fft", 1 << 21, 2, "f32"), ("fft", 1 << 22, 2, "f32"),
                                      ("fft", 8192, 2, "f64"), ("fft", 16384, 2, "f64"), ("fft", 1 << 15, 2, "f64"), ("fft", 1 << 20, 2, "f64"),
-                                     ("conv", 8192, 2, "f64"), ("conv", 16384, 2, "f64")):
+                                     ("conv", 8192, 2, "f64"), ("conv", 16384, 2, "f64"),
+                                     # the register-pass families (2048- / 1024-point tiles): the reference's own test size and a small one
+                                     ("fft", 64, 2, "f32"), ("fft", 1024, 2, "f32"), ("fft", 1024, 4, "f32"), ("fft", 64, 2, "f64"), ("fft", 1024, 2, "f64")):
             args.n, args.radix, args.precision = n, radix, prec
             r = measure(name, sd, torch, dev, args, dist, args.steps, args.warmup)
             extras.append({"what": f"{name} n={n} radix={radix}" + (" f64" if prec == "f64" else ""), **compact(r)})
