@@ -21,7 +21,7 @@ namespace sdsp_hip
 {
 namespace
 {
-constexpr int kThreads = 256;
+constexpr int kThreads = 256; // the largest workgroup (long filters, f32 up to 16 taps); TH = 128 otherwise (launch_fir)
 constexpr int kOut = 16; // outputs per thread = LDS block length
 
 template <typename R> struct vec_of;
@@ -216,8 +216,8 @@ struct fir_kargs {
 };
 
 // h is its own __restrict__ parameter so that the coefficient reads become scalar (s_load) instructions
-template <typename R, bool NT, bool PACKED, int OCC>
-__global__ __launch_bounds__(kThreads, OCC) void sdsp_fir_kernel(fir_kargs a, const R *__restrict__ h)
+template <typename R, bool NT, bool PACKED, int OCC, int TH = kThreads>
+__global__ __launch_bounds__(TH, OCC) void sdsp_fir_kernel(fir_kargs a, const R *__restrict__ h)
 {
     using V = typename vec_of<R>::type;
     constexpr int L = vec_of<R>::lanes;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kThreads, OCC) void sdsp_fir_kernel(fir_kargs a, co
     const uint32_t tpr = 1u << a.tpr_log2;
     const uint32_t row = threadIdx.x >> a.tpr_log2;
     const uint32_t t = threadIdx.x & (tpr - 1);
-    const uint32_t rows_per_wg = kThreads >> a.tpr_log2;
+    const uint32_t rows_per_wg = (uint32_t)TH >> a.tpr_log2;
     const uint64_t ch = static_cast<uint64_t>(blockIdx.x) * rows_per_wg + row;
     const bool live = ch < a.channels;
     const uint32_t block_len = tpr * kOut;
@@ -342,13 +342,13 @@ uint32_t ceil_log2(uint64_t v)
 }
 } // namespace
 
-size_t fir_lds_bytes(int precision, uint32_t taps, uint32_t tpr_log2)
+size_t fir_lds_bytes(int precision, uint32_t taps, uint32_t tpr_log2, uint32_t threads)
 {
     const uint32_t hist = kOut * ((taps + kOut - 1) / kOut);
     const uint32_t elems = hist + (kOut << tpr_log2);
     const uint32_t pad = precision == SDSP_HIP_F64 ? vec_of<double>::pad : vec_of<float>::pad;
     const size_t line = elems + (elems >> 4) * pad;
-    return line * (kThreads >> tpr_log2) * (precision == SDSP_HIP_F64 ? 8 : 4);
+    return line * (threads >> tpr_log2) * (precision == SDSP_HIP_F64 ? 8 : 4);
 }
 
 int launch_fir(int precision, const fir_args &fa, int variant, void *stream_v)
@@ -368,14 +368,20 @@ int launch_fir(int precision, const fir_args &fa, int variant, void *stream_v)
     const uint32_t lmin = ceil_log2(k.hist / kOut);
     if (l < lmin)
         l = lmin;
-    if (l > 8)
-        l = 8;
     if (lmin > 8)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many taps");
+    // Workgroups of 128 threads (rows in blocks of at most 2048 samples, half the LDS, twice the workgroups per CU) where they measured
+    // faster -- the register-pass FFT families' finding (fft_reg.hip), one call, 1M channels x 4096 samples: f32 32 / 64 taps 70.4 / 53.0 %
+    // of HBM peak against 63.3 / 49.9 % with 256 threads, f64 16 / 32 taps 72.3 / 60.5 against 69 / 52 %; f32 with up to 16 taps keeps 256
+    // (74.4 against 71.3 %), and so do filters whose history needs more than 128 threads per row (> 2048 taps)
+    const bool small = lmin <= 7 && (precision == SDSP_HIP_F64 || fa.taps > 16);
+    const uint32_t lmax = small ? 7 : 8, threads = small ? 128 : 256;
+    if (l > lmax)
+        l = lmax;
     k.tpr_log2 = l;
     k.vec_ok = (reinterpret_cast<uintptr_t>(fa.data) % 16 == 0 && (fa.stride * rs) % 16 == 0) ? 1 : 0;
-    const size_t lds = fir_lds_bytes(precision, fa.taps, l);
-    const uint32_t rows_per_wg = kThreads >> l;
+    const size_t lds = fir_lds_bytes(precision, fa.taps, l, threads);
+    const uint32_t rows_per_wg = threads >> l;
     const uint64_t grid = (fa.channels + rows_per_wg - 1) / rows_per_wg;
     if (grid > 0x7fffffffull)
         return fail(SDSP_HIP_ERR_UNSUPPORTED, "too many channels for one launch");
@@ -386,7 +392,7 @@ int launch_fir(int precision, const fir_args &fa, int variant, void *stream_v)
             if (e != hipSuccess)
                 return fail(SDSP_HIP_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kThreads), lds, stream, k, hp);
+        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, k, hp);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(SDSP_HIP_ERR_HIP, std::string("fir launch: ") + hipGetErrorString(e));
@@ -395,11 +401,22 @@ int launch_fir(int precision, const fir_args &fa, int variant, void *stream_v)
     if (precision == SDSP_HIP_F64) {
         const double *hp = static_cast<const double *>(fa.h);
         // f64: multiply + add per tap (bit-exact order); 209 VGPRs, two waves per SIMD
+        if (small)
+            return variant == 1 ? run(sdsp_fir_kernel<double, false, false, 2, 128>, hp) : run(sdsp_fir_kernel<double, true, false, 2, 128>, hp);
         return variant == 1 ? run(sdsp_fir_kernel<double, false, false, 2>, hp) : run(sdsp_fir_kernel<double, true, false, 2>, hp);
     }
     const float *hp = static_cast<const float *>(fa.h);
     // f32 (measured, 1M channels x 4096 samples, % of 8 TB/s): one FMA per tap at 120 VGPRs / 4 waves per
     // SIMD: 16 taps 76 %, 32 taps 66 %, 64 taps 46 %; packed FMAs at 128 VGPRs: 74 / 65 / 50 %
+    if (small) {
+        switch (variant) {
+        case 1: return run(sdsp_fir_kernel<float, false, false, 4, 128>, hp); // default cache policy
+        case 2: return run(sdsp_fir_kernel<float, true, true, 4, 128>, hp);
+        case 3: return run(sdsp_fir_kernel<float, true, false, 4, 128>, hp);
+        default:
+            return fa.taps < 48 ? run(sdsp_fir_kernel<float, true, false, 4, 128>, hp) : run(sdsp_fir_kernel<float, true, true, 4, 128>, hp);
+        }
+    }
     switch (variant) {
     case 1: return run(sdsp_fir_kernel<float, false, false, 4>, hp); // default cache policy
     case 2: return run(sdsp_fir_kernel<float, true, true, 4>, hp);
